@@ -1,0 +1,16 @@
+"""eve_amd -- MI355X-native implementation of EVE's modality-aware MoE layer.
+
+Public names mirror the reference (models/layer.py, models/sharded_moe.py,
+models/experts.py, models/multiway_transformer.py:44-55):
+
+    from eve_amd import MoE, MOELayer, TopKGate, Experts, MultiwayTransformerMLP
+
+All computation happens in hand-written HIP kernels (eve_amd/csrc, gfx950) reached through
+the C ABI of libeve_moe.so (include/eve_moe.h).
+"""
+from .experts import ACT2FN, Experts, MultiwayTransformerMLP, QuickGELU
+from .layer import MoE
+from .sharded_moe import MOELayer, TopKGate, gumbel_rsample, top2gating
+
+__all__ = ["MoE", "MOELayer", "TopKGate", "Experts", "MultiwayTransformerMLP", "QuickGELU", "ACT2FN",
+           "gumbel_rsample", "top2gating"]

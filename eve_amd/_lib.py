@@ -1,0 +1,74 @@
+"""ctypes binding of libeve_moe.so (C ABI declared in include/eve_moe.h).
+
+The shared library is built in-tree by `__graft_entry__.build()` / `eve_amd/build.py`
+(hipcc --offload-arch=gfx950).  There is NO fallback: if the library is missing or a call
+fails, a RuntimeError is raised -- nothing in this package computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeve_moe.so")
+
+F32, BF16 = 0, 1
+MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3
+ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
+ABI_VERSION = 1
+
+_P, _I, _Z = c_void_p, c_int, c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/eve_moe.h declares
+SIGNATURES = {
+    "eve_moe_abi_version": (c_int, []),
+    "eve_moe_last_error": (c_char_p, []),
+    "eve_capacity": (c_int, [_I, _I, c_double, _I]),
+    "eve_gate_logits_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eve_gate_workspace_bytes": (c_size_t, [_I, _I]),
+    "eve_gate_top2_fwd": (c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "eve_gate_top2_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "eve_gate_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "eve_gate_wgrad": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "eve_dispatch_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eve_dispatch_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "eve_embed_grad_workspace_bytes": (c_size_t, [_I, _I]),
+    "eve_embed_grad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "eve_combine_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "eve_combine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "eve_ffn_fwd": (c_int, [_P] * 9 + [_I] * 7 + [_P]),
+    "eve_ffn_bwd": (c_int, [_P] * 13 + [_I] * 7 + [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly when it is absent or the ABI does not match."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"eve_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.eve_moe_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"eve_amd: libeve_moe.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.eve_moe_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")

@@ -1,0 +1,48 @@
+"""Build libeve_moe.so in-tree: hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libeve_moe.so")
+SOURCES = ["capi.hip", "gate.hip", "permute.hip", "ffn.hip", "ffn_mfma.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "eve_moe.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return OUT
+    objs = []
+    bdir = os.path.join(HERE, "..", "build", "obj")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = ["hipcc", *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

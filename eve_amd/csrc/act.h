@@ -1,0 +1,34 @@
+// Expert activations (models/multiway_transformer.py:47, ACT2FN[hidden_act]) and derivatives.
+#pragma once
+#include "common.h"
+
+namespace eve {
+
+template <bool FAST> __device__ __forceinline__ float exp_(float x) { if constexpr (FAST) return __expf(x); else return expf(x); }
+
+template <int ACT, bool FAST> __device__ __forceinline__ float act_fwd(float z) {
+  if constexpr (ACT == EVE_ACT_QUICK_GELU) {
+    return z / (1.f + exp_<FAST>(-1.702f * z));  // z * sigmoid(1.702 z)
+  } else if constexpr (ACT == EVE_ACT_GELU) {
+    return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
+  } else if constexpr (ACT == EVE_ACT_RELU) {
+    return z > 0.f ? z : 0.f;
+  } else {
+    return z;
+  }
+}
+
+template <int ACT, bool FAST> __device__ __forceinline__ float act_bwd(float z) {
+  if constexpr (ACT == EVE_ACT_QUICK_GELU) {
+    const float s = 1.f / (1.f + exp_<FAST>(-1.702f * z));
+    return s * (1.f + 1.702f * z * (1.f - s));
+  } else if constexpr (ACT == EVE_ACT_GELU) {
+    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * exp_<FAST>(-0.5f * z * z);
+  } else if constexpr (ACT == EVE_ACT_RELU) {
+    return z > 0.f ? 1.f : 0.f;
+  } else {
+    return 1.f;
+  }
+}
+
+}  // namespace eve

@@ -1,0 +1,116 @@
+// Shared helpers for the eve_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/eve_moe.h"
+
+namespace eve {
+
+typedef __bf16 bf16_t;
+
+constexpr int kWave = 64;
+
+// ---- error plumbing -------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define EVE_REQUIRE(cond, code, ...)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::eve::set_error(__VA_ARGS__);        \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+#define EVE_CHECK_LAUNCH(name)                                                         \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) {                                                            \
+      ::eve::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));          \
+      return EVE_ERR_LAUNCH;                                                           \
+    }                                                                                  \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- element conversion ---------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return static_cast<float>(v); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return static_cast<bf16_t>(v); }  // RNE
+
+// 16-byte vector of T: 4 floats or 8 bf16.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  float4 raw;
+  __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
+  __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = v; }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    uint32_t w = (&raw.x)[i >> 1];
+    uint32_t bits = (i & 1) ? (w & 0xffff0000u) : (w << 16);
+    return __uint_as_float(bits);
+  }
+  __device__ __forceinline__ void set(int i, float v) {
+    bf16_t b = static_cast<bf16_t>(v);
+    uint32_t h = (uint32_t)__builtin_bit_cast(unsigned short, b);
+    uint32_t& w = (&raw.x)[i >> 1];
+    w = (i & 1) ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
+  }
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
+  Vec16<T> v;
+  v.raw = *reinterpret_cast<const decltype(v.raw)*>(p);
+  return v;
+}
+template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<decltype(v.raw)*>(p) = v.raw;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+  Vec16<T> v;
+  v.raw.x = 0; v.raw.y = 0; v.raw.z = 0; v.raw.w = 0;
+  return v;
+}
+template <> __device__ __forceinline__ Vec16<float> zero16<float>() {
+  Vec16<float> v;
+  v.raw = make_float4(0.f, 0.f, 0.f, 0.f);
+  return v;
+}
+
+// ---- wave primitives (64 lanes) ---------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (l >= o) v += t;
+  }
+  return v;
+}
+
+// modality of token s (row-major (b,t) flattening): 0 vision, 1 text.  mode: EVE_MODE_*
+__device__ __forceinline__ int token_modality(int s, int T, int n_vis, int mode) {
+  if (mode == EVE_MODE_VISION) return 0;
+  if (mode == EVE_MODE_TEXT) return 1;
+  return (s % T) < n_vis ? 0 : 1;
+}
+
+}  // namespace eve

@@ -1,0 +1,352 @@
+// Dispatch / combine permutes: the coalesced row gathers that replace the reference's dense
+// one-hot einsums (models/sharded_moe.py:367 and :377) and their autograd backward, plus the
+// modality-embedding gradient.  HBM-bound row movers: one wave per row, 16 B per lane.
+#include "common.h"
+
+namespace eve {
+
+constexpr int kRowsPerWave = 2;  // rows in flight per wave iteration
+
+// ----------------------------------------------------------------------------- dispatch fwd
+// xd[slot] = round(h[tok] + emb(tok)) or 0.  One wave per slot row.
+template <typename T>
+__global__ __launch_bounds__(256) void dispatch_fwd_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
+                                                           const T* __restrict__ temb,
+                                                           const int32_t* __restrict__ slot_token, T* __restrict__ xd,
+                                                           int T_, int n_vis, int mode, int M, int num_slots) {
+  constexpr int N = Vec16<T>::N;
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int chunks = M / N;
+  for (int slot = wave; slot < num_slots; slot += nwaves) {
+    const int tok = slot_token[slot];
+    T* dst = xd + (size_t)slot * M;
+    if (tok < 0) {
+      for (int c = lane; c < chunks; c += 64) store16<T>(dst + c * N, zero16<T>());
+      continue;
+    }
+    const T* src = h + (size_t)tok * M;
+    const T* emb = nullptr;
+    if (mode != EVE_MODE_NONE) emb = token_modality(tok, T_, n_vis, mode) ? temb : vemb;
+    for (int c = lane; c < chunks; c += 64) {
+      Vec16<T> v = load16<T>(src + c * N);
+      if (emb) {
+        const Vec16<T> e = load16<T>(emb + c * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v.set(j, v.get(j) + e.get(j));
+      }
+      store16<T>(dst + c * N, v);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- dispatch bwd
+// dh[s] = dxd[slot1] + dxd[slot2] + dlogits[s,:] @ wg.  One wave per token.
+template <typename T>
+__global__ __launch_bounds__(256) void dispatch_bwd_kernel(const T* __restrict__ dxd, const int32_t* __restrict__ slot,
+                                                           const float* __restrict__ dlogits,
+                                                           const float* __restrict__ wg, T* __restrict__ dh, int S,
+                                                           int M, int E) {
+  constexpr int N = Vec16<T>::N;
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int chunks = M / N;
+  for (int s = wave; s < S; s += nwaves) {
+    const int s1 = slot[2 * s], s2 = slot[2 * s + 1];
+    const float* dl = dlogits ? dlogits + (size_t)s * E : nullptr;
+    for (int c = lane; c < chunks; c += 64) {
+      float acc[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] = 0.f;
+      if (s1 >= 0) {
+        const Vec16<T> v = load16<T>(dxd + (size_t)s1 * M + c * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += v.get(j);
+      }
+      if (s2 >= 0) {
+        const Vec16<T> v = load16<T>(dxd + (size_t)s2 * M + c * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += v.get(j);
+      }
+      if (dl) {
+        for (int e = 0; e < E; ++e) {
+          const float d = dl[e];
+          const float* w = wg + (size_t)e * M + c * N;
+#pragma unroll
+          for (int j = 0; j < N; j += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + j);
+            acc[j] = fmaf(d, wv.x, acc[j]);
+            acc[j + 1] = fmaf(d, wv.y, acc[j + 1]);
+            acc[j + 2] = fmaf(d, wv.z, acc[j + 2]);
+            acc[j + 3] = fmaf(d, wv.w, acc[j + 3]);
+          }
+        }
+      }
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < N; ++j) o.set(j, acc[j]);
+      store16<T>(dh + (size_t)s * M + c * N, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ combine fwd
+template <typename T>
+__global__ __launch_bounds__(256) void combine_fwd_kernel(const T* __restrict__ y, const int32_t* __restrict__ slot,
+                                                          const float* __restrict__ weight, T* __restrict__ out, int S,
+                                                          int M) {
+  constexpr int N = Vec16<T>::N;
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int chunks = M / N;
+  for (int s = wave; s < S; s += nwaves) {
+    const int s1 = slot[2 * s], s2 = slot[2 * s + 1];
+    const float w1 = weight[2 * s], w2 = weight[2 * s + 1];
+    for (int c = lane; c < chunks; c += 64) {
+      float acc[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] = 0.f;
+      if (s1 >= 0) {
+        const Vec16<T> v = load16<T>(y + (size_t)s1 * M + c * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = w1 * v.get(j);
+      }
+      if (s2 >= 0) {
+        const Vec16<T> v = load16<T>(y + (size_t)s2 * M + c * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = fmaf(w2, v.get(j), acc[j]);
+      }
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < N; ++j) o.set(j, acc[j]);
+      store16<T>(out + (size_t)s * M + c * N, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ combine bwd
+// (a) per slot: dy[slot] = slot_weight * dout[tok] (0 when empty);
+template <typename T>
+__global__ __launch_bounds__(256) void combine_bwd_dy_kernel(const T* __restrict__ dout,
+                                                             const int32_t* __restrict__ slot_token,
+                                                             const float* __restrict__ slot_weight,
+                                                             T* __restrict__ dy, int M, int num_slots) {
+  constexpr int N = Vec16<T>::N;
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int chunks = M / N;
+  for (int sl = wave; sl < num_slots; sl += nwaves) {
+    const int tok = slot_token[sl];
+    T* dst = dy + (size_t)sl * M;
+    if (tok < 0) {
+      for (int c = lane; c < chunks; c += 64) store16<T>(dst + c * N, zero16<T>());
+      continue;
+    }
+    const float w = slot_weight[sl];
+    const T* src = dout + (size_t)tok * M;
+    for (int c = lane; c < chunks; c += 64) {
+      Vec16<T> v = load16<T>(src + c * N);
+#pragma unroll
+      for (int j = 0; j < N; ++j) v.set(j, w * v.get(j));
+      store16<T>(dst + c * N, v);
+    }
+  }
+}
+
+// (b) per token: d_weight[s,k] = <dout[s], y[slot_k]>.
+template <typename T>
+__global__ __launch_bounds__(256) void combine_bwd_dw_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                             const int32_t* __restrict__ slot,
+                                                             float* __restrict__ d_weight, int S, int M) {
+  constexpr int N = Vec16<T>::N;
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int chunks = M / N;
+  for (int s = wave; s < S; s += nwaves) {
+    const int s1 = slot[2 * s], s2 = slot[2 * s + 1];
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = lane; c < chunks; c += 64) {
+      const Vec16<T> d = load16<T>(dout + (size_t)s * M + c * N);
+      if (s1 >= 0) {
+        const Vec16<T> v = load16<T>(y + (size_t)s1 * M + c * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) a1 = fmaf(d.get(j), v.get(j), a1);
+      }
+      if (s2 >= 0) {
+        const Vec16<T> v = load16<T>(y + (size_t)s2 * M + c * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) a2 = fmaf(d.get(j), v.get(j), a2);
+      }
+    }
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) {
+      d_weight[2 * s] = a1;
+      d_weight[2 * s + 1] = a2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ modality embed gradient
+// Column sums of dh by modality.  Stage 1: block (chunk of TS tokens) x (column tile of 256
+// columns) -> part[chunk][2][M]; stage 2: fixed-order sum over chunks.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_grad_partial_kernel(const T* __restrict__ dh, float* __restrict__ part,
+                                                                 int S, int T_, int n_vis, int mode, int M, int TS) {
+  const int col = blockIdx.y * blockDim.x + threadIdx.x;
+  if (col >= M) return;
+  const int s0 = blockIdx.x * TS, s1 = min(S, s0 + TS);
+  float av = 0.f, at = 0.f;
+  for (int s = s0; s < s1; ++s) {
+    const float v = to_f32<T>(dh[(size_t)s * M + col]);
+    if (token_modality(s, T_, n_vis, mode)) at += v; else av += v;
+  }
+  part[((size_t)blockIdx.x * 2 + 0) * M + col] = av;
+  part[((size_t)blockIdx.x * 2 + 1) * M + col] = at;
+}
+
+__global__ __launch_bounds__(256) void embed_grad_final_kernel(const float* __restrict__ part, float* __restrict__ dv,
+                                                               float* __restrict__ dt, int M, int nchunks) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= M) return;
+  float av = 0.f, at = 0.f;
+  for (int b = 0; b < nchunks; ++b) {
+    av += part[((size_t)b * 2 + 0) * M + col];
+    at += part[((size_t)b * 2 + 1) * M + col];
+  }
+  if (dv) dv[col] = av;
+  if (dt) dt[col] = at;
+}
+
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int row_grid(int rows) { return max(1, min(ceil_div(rows, 4), 4096)); }
+
+static int check_rows(const char* who, int M, int dtype) {
+  const int n = dtype == EVE_BF16 ? 8 : 4;
+  if (dtype != EVE_F32 && dtype != EVE_BF16) { set_error("%s: bad dtype %d", who, dtype); return EVE_ERR_ARG; }
+  if (M <= 0 || M % n != 0) { set_error("%s: M=%d must be a positive multiple of %d", who, M, n); return EVE_ERR_ARG; }
+  return EVE_OK;
+}
+
+}  // namespace eve
+
+using namespace eve;
+
+#define EVE_DISPATCH_DTYPE(dtype, KERNEL, grid, block, st, ...)                                     \
+  do {                                                                                              \
+    if ((dtype) == EVE_F32) hipLaunchKernelGGL((KERNEL<float>), grid, block, 0, st, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((KERNEL<bf16_t>), grid, block, 0, st, __VA_ARGS__);                     \
+  } while (0)
+
+extern "C" int eve_dispatch_fwd(const void* h, const void* vision_embed, const void* text_embed,
+                                const int32_t* slot_token, void* xd, int S, int T, int n_vis, int mode, int M,
+                                int num_slots, int dtype, void* stream) {
+  EVE_REQUIRE(h && slot_token && xd, EVE_ERR_ARG, "eve_dispatch_fwd: null pointer");
+  EVE_REQUIRE(S > 0 && num_slots > 0, EVE_ERR_ARG, "eve_dispatch_fwd: bad shape");
+  if (int rc = check_rows("eve_dispatch_fwd", M, dtype)) return rc;
+  if (mode != EVE_MODE_NONE)
+    EVE_REQUIRE(vision_embed && text_embed && T > 0 && S % T == 0, EVE_ERR_ARG, "eve_dispatch_fwd: embeddings / T required for mode %d", mode);
+  hipStream_t st = S_(stream);
+  if (dtype == EVE_F32)
+    hipLaunchKernelGGL((dispatch_fwd_kernel<float>), dim3(row_grid(num_slots)), dim3(256), 0, st, (const float*)h,
+                       (const float*)vision_embed, (const float*)text_embed, slot_token, (float*)xd, T, n_vis, mode, M,
+                       num_slots);
+  else
+    hipLaunchKernelGGL((dispatch_fwd_kernel<bf16_t>), dim3(row_grid(num_slots)), dim3(256), 0, st, (const bf16_t*)h,
+                       (const bf16_t*)vision_embed, (const bf16_t*)text_embed, slot_token, (bf16_t*)xd, T, n_vis, mode,
+                       M, num_slots);
+  EVE_CHECK_LAUNCH("dispatch_fwd_kernel");
+  return EVE_OK;
+}
+
+extern "C" int eve_dispatch_bwd(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh,
+                                int S, int M, int E, int dtype, void* stream) {
+  EVE_REQUIRE(dxd && slot && dh, EVE_ERR_ARG, "eve_dispatch_bwd: null pointer");
+  EVE_REQUIRE(!dlogits || wg, EVE_ERR_ARG, "eve_dispatch_bwd: wg required with dlogits");
+  EVE_REQUIRE(S > 0 && E > 0, EVE_ERR_ARG, "eve_dispatch_bwd: bad shape");
+  if (int rc = check_rows("eve_dispatch_bwd", M, dtype)) return rc;
+  hipStream_t st = S_(stream);
+  if (dtype == EVE_F32)
+    hipLaunchKernelGGL((dispatch_bwd_kernel<float>), dim3(row_grid(S)), dim3(256), 0, st, (const float*)dxd, slot,
+                       dlogits, wg, (float*)dh, S, M, E);
+  else
+    hipLaunchKernelGGL((dispatch_bwd_kernel<bf16_t>), dim3(row_grid(S)), dim3(256), 0, st, (const bf16_t*)dxd, slot,
+                       dlogits, wg, (bf16_t*)dh, S, M, E);
+  EVE_CHECK_LAUNCH("dispatch_bwd_kernel");
+  return EVE_OK;
+}
+
+extern "C" int eve_combine_fwd(const void* y, const int32_t* slot, const float* weight, void* out, int S, int M,
+                               int dtype, void* stream) {
+  EVE_REQUIRE(y && slot && weight && out, EVE_ERR_ARG, "eve_combine_fwd: null pointer");
+  EVE_REQUIRE(S > 0, EVE_ERR_ARG, "eve_combine_fwd: bad shape");
+  if (int rc = check_rows("eve_combine_fwd", M, dtype)) return rc;
+  hipStream_t st = S_(stream);
+  if (dtype == EVE_F32)
+    hipLaunchKernelGGL((combine_fwd_kernel<float>), dim3(row_grid(S)), dim3(256), 0, st, (const float*)y, slot, weight,
+                       (float*)out, S, M);
+  else
+    hipLaunchKernelGGL((combine_fwd_kernel<bf16_t>), dim3(row_grid(S)), dim3(256), 0, st, (const bf16_t*)y, slot,
+                       weight, (bf16_t*)out, S, M);
+  EVE_CHECK_LAUNCH("combine_fwd_kernel");
+  return EVE_OK;
+}
+
+extern "C" int eve_combine_bwd(const void* dout, const void* y, const int32_t* slot, const int32_t* slot_token,
+                               const float* slot_weight, void* dy, float* d_weight, int S, int M, int num_slots,
+                               int dtype, void* stream) {
+  EVE_REQUIRE(dout && y && slot && slot_token && slot_weight && dy && d_weight, EVE_ERR_ARG, "eve_combine_bwd: null pointer");
+  EVE_REQUIRE(S > 0 && num_slots > 0, EVE_ERR_ARG, "eve_combine_bwd: bad shape");
+  if (int rc = check_rows("eve_combine_bwd", M, dtype)) return rc;
+  hipStream_t st = S_(stream);
+  if (dtype == EVE_F32) {
+    hipLaunchKernelGGL((combine_bwd_dy_kernel<float>), dim3(row_grid(num_slots)), dim3(256), 0, st, (const float*)dout,
+                       slot_token, slot_weight, (float*)dy, M, num_slots);
+    hipLaunchKernelGGL((combine_bwd_dw_kernel<float>), dim3(row_grid(S)), dim3(256), 0, st, (const float*)dout,
+                       (const float*)y, slot, d_weight, S, M);
+  } else {
+    hipLaunchKernelGGL((combine_bwd_dy_kernel<bf16_t>), dim3(row_grid(num_slots)), dim3(256), 0, st,
+                       (const bf16_t*)dout, slot_token, slot_weight, (bf16_t*)dy, M, num_slots);
+    hipLaunchKernelGGL((combine_bwd_dw_kernel<bf16_t>), dim3(row_grid(S)), dim3(256), 0, st, (const bf16_t*)dout,
+                       (const bf16_t*)y, slot, d_weight, S, M);
+  }
+  EVE_CHECK_LAUNCH("combine_bwd kernels");
+  return EVE_OK;
+}
+
+static const int kEmbedTS = 128;
+
+extern "C" size_t eve_embed_grad_workspace_bytes(int S, int M) {
+  if (S <= 0 || M <= 0) return 0;
+  return (size_t)ceil_div(S, kEmbedTS) * 2 * M * sizeof(float);
+}
+
+extern "C" int eve_embed_grad(const void* dh, float* dvision, float* dtext, int S, int T, int n_vis, int mode, int M,
+                              int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  EVE_REQUIRE(dh && workspace, EVE_ERR_ARG, "eve_embed_grad: null pointer");
+  EVE_REQUIRE(mode != EVE_MODE_NONE, EVE_ERR_ARG, "eve_embed_grad: mode NONE has no embeddings");
+  EVE_REQUIRE(S > 0 && T > 0 && S % T == 0, EVE_ERR_ARG, "eve_embed_grad: bad shape");
+  if (int rc = check_rows("eve_embed_grad", M, dtype)) return rc;
+  const size_t need = eve_embed_grad_workspace_bytes(S, M);
+  EVE_REQUIRE(workspace_bytes >= need, EVE_ERR_WORKSPACE, "eve_embed_grad: workspace %zu < %zu", workspace_bytes, need);
+  const int nchunks = ceil_div(S, kEmbedTS);
+  float* part = static_cast<float*>(workspace);
+  hipStream_t st = S_(stream);
+  dim3 grid(nchunks, ceil_div(M, 256));
+  if (dtype == EVE_F32)
+    hipLaunchKernelGGL((embed_grad_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)dh, part, S, T, n_vis,
+                       mode, M, kEmbedTS);
+  else
+    hipLaunchKernelGGL((embed_grad_partial_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dh, part, S, T,
+                       n_vis, mode, M, kEmbedTS);
+  EVE_CHECK_LAUNCH("embed_grad_partial_kernel");
+  hipLaunchKernelGGL(embed_grad_final_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, part, dvision, dtext, M,
+                     nchunks);
+  EVE_CHECK_LAUNCH("embed_grad_final_kernel");
+  return EVE_OK;
+}

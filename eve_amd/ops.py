@@ -1,0 +1,206 @@
+"""Tensor-level wrappers over the C ABI (include/eve_moe.h).
+
+Each function checks device / dtype / contiguity, allocates outputs with torch (device
+memory and streams are the only things PyTorch is used for here) and enqueues the HIP
+kernels on the current stream.  No function here has a CPU implementation.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+MODES = {None: _lib.MODE_NONE, "none": _lib.MODE_NONE, "vl": _lib.MODE_VL, "vision": _lib.MODE_VISION,
+         "text": _lib.MODE_TEXT}
+ACTS = {"quick_gelu": _lib.ACT_QUICK_GELU, "gelu": _lib.ACT_GELU, "relu": _lib.ACT_RELU,
+        "identity": _lib.ACT_IDENTITY}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError(f"eve_amd: unsupported dtype {t.dtype} (float32 or bfloat16)") from None
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"eve_amd: `{name}` must live on a GPU (got {t.device}); there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError(f"eve_amd: `{name}` must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"eve_amd: `{name}` must be {dtype}, got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def capacity(S: int, E: int, capacity_factor: float, min_capacity: int) -> int:
+    """models/sharded_moe.py:150-160,:177 (host arithmetic inside the library)."""
+    return int(_lib.load().eve_capacity(int(S), int(E), float(capacity_factor), int(min_capacity)))
+
+
+@dataclass
+class Routing:
+    """Index-form result of top-2 gating (replaces combine_weights / dispatch_mask [S,E,C])."""
+    S: int
+    E: int
+    C: int
+    gates: torch.Tensor        # [S,E] f32
+    idx: torch.Tensor          # [S,2] i32
+    loc: torch.Tensor          # [S,2] i32
+    slot: torch.Tensor         # [S,2] i32 (-1 = not dispatched)
+    weight: torch.Tensor       # [S,2] f32
+    slot_token: torch.Tensor   # [E*C] i32 (-1 = empty)
+    slot_weight: torch.Tensor  # [E*C] f32
+    exp_counts: torch.Tensor   # [E] i64 (device)
+    rows: torch.Tensor         # [E] i32
+    l_aux: torch.Tensor        # [1] f32
+
+
+def gate_logits(h2d: torch.Tensor, vemb, temb, wg: torch.Tensor, T: int, n_vis: int, mode: int) -> torch.Tensor:
+    _chk(h2d, "hidden"), _chk(wg, "wg", torch.float32)
+    _chk(vemb, "vision_embed", h2d.dtype), _chk(temb, "text_embed", h2d.dtype)
+    S, M = h2d.shape
+    E = wg.shape[0]
+    assert wg.shape[1] == M
+    logits = torch.empty(S, E, dtype=torch.float32, device=h2d.device)
+    _lib.call("eve_gate_logits_fwd", _p(h2d), _p(vemb), _p(temb), _p(wg), _p(logits), S, T, n_vis, mode, M, E,
+              _dt(h2d), _stream())
+    return logits
+
+
+def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int) -> Routing:
+    _chk(logits, "logits", torch.float32), _chk(noise, "noise", torch.float32)
+    S, E = logits.shape
+    assert noise.shape == logits.shape
+    dev = logits.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    r = Routing(S, E, C, torch.empty(S, E, **f32), torch.empty(S, 2, **i32), torch.empty(S, 2, **i32),
+                torch.empty(S, 2, **i32), torch.empty(S, 2, **f32), torch.empty(E * C, **i32),
+                torch.zeros(E * C, **f32), torch.empty(E, dtype=torch.int64, device=dev), torch.empty(E, **i32),
+                torch.empty(1, **f32))
+    nbytes = _lib.load().eve_gate_workspace_bytes(S, E)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.call("eve_gate_top2_fwd", _p(logits), _p(noise), S, E, C, _p(r.gates), _p(r.idx), _p(r.loc), _p(r.slot),
+              _p(r.weight), _p(r.slot_token), _p(r.slot_weight), _p(r.exp_counts), _p(r.rows), _p(r.l_aux), _p(ws),
+              nbytes, _stream())
+    return r
+
+
+def gate_top2_bwd(r: Routing, d_weight: torch.Tensor, d_l_aux: Optional[torch.Tensor]) -> torch.Tensor:
+    _chk(d_weight, "d_weight", torch.float32), _chk(d_l_aux, "d_l_aux", torch.float32)
+    dlogits = torch.empty(r.S, r.E, dtype=torch.float32, device=r.gates.device)
+    _lib.call("eve_gate_top2_bwd", _p(r.gates), _p(r.idx), _p(r.loc), _p(d_weight), _p(d_l_aux), _p(r.exp_counts),
+              r.S, r.E, r.C, _p(dlogits), _stream())
+    return dlogits
+
+
+def gate_wgrad(h2d, vemb, temb, dlogits, T: int, n_vis: int, mode: int) -> torch.Tensor:
+    _chk(h2d, "hidden"), _chk(dlogits, "dlogits", torch.float32)
+    S, M = h2d.shape
+    E = dlogits.shape[1]
+    dwg = torch.empty(E, M, dtype=torch.float32, device=h2d.device)
+    nbytes = _lib.load().eve_gate_wgrad_workspace_bytes(S, M, E)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h2d.device)
+    _lib.call("eve_gate_wgrad", _p(h2d), _p(vemb), _p(temb), _p(dlogits), _p(dwg), S, T, n_vis, mode, M, E, _dt(h2d),
+              _p(ws), nbytes, _stream())
+    return dwg
+
+
+def dispatch_fwd(h2d, vemb, temb, slot_token: torch.Tensor, T: int, n_vis: int, mode: int) -> torch.Tensor:
+    _chk(h2d, "hidden"), _chk(slot_token, "slot_token", torch.int32)
+    S, M = h2d.shape
+    n = slot_token.numel()
+    xd = torch.empty(n, M, dtype=h2d.dtype, device=h2d.device)
+    _lib.call("eve_dispatch_fwd", _p(h2d), _p(vemb), _p(temb), _p(slot_token), _p(xd), S, T, n_vis, mode, M, n,
+              _dt(h2d), _stream())
+    return xd
+
+
+def dispatch_bwd(dxd: torch.Tensor, slot: torch.Tensor, dlogits, wg, S: int) -> torch.Tensor:
+    _chk(dxd, "dxd"), _chk(slot, "slot", torch.int32), _chk(dlogits, "dlogits", torch.float32)
+    _chk(wg, "wg", torch.float32)
+    M = dxd.shape[-1]
+    E = wg.shape[0] if wg is not None else 1
+    dh = torch.empty(S, M, dtype=dxd.dtype, device=dxd.device)
+    _lib.call("eve_dispatch_bwd", _p(dxd), _p(slot), _p(dlogits), _p(wg), _p(dh), S, M, E, _dt(dxd), _stream())
+    return dh
+
+
+def embed_grad(dh: torch.Tensor, T: int, n_vis: int, mode: int, want_v=True, want_t=True):
+    _chk(dh, "dh")
+    S, M = dh.shape
+    dv = torch.empty(M, dtype=torch.float32, device=dh.device) if want_v else None
+    dt = torch.empty(M, dtype=torch.float32, device=dh.device) if want_t else None
+    nbytes = _lib.load().eve_embed_grad_workspace_bytes(S, M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dh.device)
+    _lib.call("eve_embed_grad", _p(dh), _p(dv), _p(dt), S, T, n_vis, mode, M, _dt(dh), _p(ws), nbytes, _stream())
+    return dv, dt
+
+
+def combine_fwd(y: torch.Tensor, slot: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    _chk(y, "expert_output"), _chk(slot, "slot", torch.int32), _chk(weight, "weight", torch.float32)
+    S = slot.shape[0]
+    M = y.shape[-1]
+    out = torch.empty(S, M, dtype=y.dtype, device=y.device)
+    _lib.call("eve_combine_fwd", _p(y), _p(slot), _p(weight), _p(out), S, M, _dt(y), _stream())
+    return out
+
+
+def combine_bwd(dout: torch.Tensor, y: torch.Tensor, slot, slot_token, slot_weight) -> Tuple[torch.Tensor, torch.Tensor]:
+    _chk(dout, "dout", y.dtype), _chk(y, "expert_output")
+    S, M = dout.shape
+    n = slot_token.numel()
+    dy = torch.empty(n, M, dtype=y.dtype, device=y.device)
+    dw = torch.empty(S, 2, dtype=torch.float32, device=y.device)
+    _lib.call("eve_combine_bwd", _p(dout), _p(y), _p(slot), _p(slot_token), _p(slot_weight), _p(dy), _p(dw), S, M, n,
+              _dt(y), _stream())
+    return dy, dw
+
+
+def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True):
+    """x [G,R,M]; w1 [E_l,I,M]; b1 [E_l,I]; w2 [E_l,M,I]; b2 [E_l,M] -> (z|None, a, y)."""
+    for t, n in ((x, "x"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+        _chk(t, n, x.dtype)
+    _chk(rows, "rows", torch.int32)
+    G, R, M = x.shape
+    E_l, I, M2 = w1.shape
+    assert M2 == M and w2.shape == (E_l, M, I) and b1.shape == (E_l, I) and b2.shape == (E_l, M) and G % E_l == 0
+    z = torch.empty(G, R, I, dtype=x.dtype, device=x.device) if save_z else None
+    a = torch.empty(G, R, I, dtype=x.dtype, device=x.device)
+    y = torch.empty(G, R, M, dtype=x.dtype, device=x.device)
+    _lib.call("eve_ffn_fwd", _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(z), _p(a), _p(y), _p(rows), G, E_l, R, M, I,
+              act, _dt(x), _stream())
+    return z, a, y
+
+
+def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int):
+    """-> (dx [G,R,M], dw1, db1, dw2, db2) with the shapes / dtype of the forward operands."""
+    for t, n in ((dy, "dy"), (x, "x"), (z, "z"), (a, "a"), (w1, "w1"), (w2, "w2")):
+        _chk(t, n, x.dtype)
+    G, R, M = x.shape
+    E_l, I, _ = w1.shape
+    dev = x.device
+    dz = torch.empty(G, R, I, dtype=x.dtype, device=dev)
+    # rows beyond rows[g] are never written by the kernels; zero so EP exchanges carry zeros
+    dx = torch.zeros(G, R, M, dtype=x.dtype, device=dev) if rows is not None else torch.empty(G, R, M, dtype=x.dtype, device=dev)
+    dw1 = torch.empty(E_l, I, M, dtype=x.dtype, device=dev)
+    db1 = torch.empty(E_l, I, dtype=x.dtype, device=dev)
+    dw2 = torch.empty(E_l, M, I, dtype=x.dtype, device=dev)
+    db2 = torch.empty(E_l, M, dtype=x.dtype, device=dev)
+    _lib.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),
+              _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _stream())
+    return dx, dw1, db1, dw2, db2

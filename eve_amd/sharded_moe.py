@@ -1,0 +1,375 @@
+"""MI355X-native gate + MoE layer behind the reference's module interface.
+
+Mirrors the public names of the reference's models/sharded_moe.py (`TopKGate`, `MOELayer`,
+`top2gating`, `gumbel_rsample`, `_AllToAll`, `_capacity`) so callers and checkpoints drop in,
+but none of its computation: the dense one-hot [S,E,C] tensors and einsums
+(reference sharded_moe.py:172-235, :367, :377) are replaced by index-form routing produced
+by the fused HIP gate kernel and by coalesced row gathers (eve_amd/csrc/*.hip through the
+C ABI in include/eve_moe.h).  Everything runs on the GPU; there is no eager fallback.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from . import _lib, ops
+
+gumbel_map: Dict[torch.device, Callable] = {}
+
+
+def trunc_normal_(tensor: Tensor, mean: float = 0.0, std: float = 1.0) -> Tensor:
+    """Truncated normal clipped at +-std (reference sharded_moe.py:43-44 via timm)."""
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=-std, b=std)
+
+
+def gumbel_rsample(shape, device: torch.device) -> Tensor:
+    """One Gumbel(0,1) draw of `shape` from the GLOBAL torch generator of `device`, exactly
+    the call the reference makes (sharded_moe.py:70-77), so RNG consumption -- and hence
+    activation-checkpoint replay -- is unchanged."""
+    device = torch.device(device)
+    sampler = gumbel_map.get(device)
+    if sampler is None:
+        sampler = torch.distributions.gumbel.Gumbel(torch.tensor(0.0, device=device),
+                                                    torch.tensor(1.0, device=device)).rsample
+        gumbel_map[device] = sampler
+    return sampler(shape)
+
+
+def _capacity(num_tokens: int, num_experts: int, capacity_factor: float, min_capacity: int) -> int:
+    """Expert queue length for `capacity_factor` ALREADY doubled by the caller, as in the
+    reference's `_capacity(gates, tensor(cf * 2), tensor(min_capacity))` (sharded_moe.py:150-160,:177)."""
+    return ops.capacity(num_tokens, num_experts, capacity_factor / 2.0, min_capacity)
+
+
+def _mode_code(mode: Optional[str], has_embed: bool) -> int:
+    if not has_embed:
+        return _lib.MODE_NONE
+    if mode == "vision":
+        return _lib.MODE_VISION
+    if mode == "text":
+        return _lib.MODE_TEXT
+    return _lib.MODE_VL  # the reference treats every other value as 'vl' (sharded_moe.py:355)
+
+
+# ------------------------------------------------------------------ autograd functions
+class _AllToAll(torch.autograd.Function):
+    """Equal-split all-to-all over the expert-parallel group (RCCL on MI355X); its backward
+    is the same exchange applied to the gradient (reference sharded_moe.py:84-100)."""
+
+    @staticmethod
+    def forward(ctx: Any, group, input: Tensor) -> Tensor:  # type: ignore[override]
+        ctx.group = group
+        input = input.contiguous()
+        output = torch.empty_like(input)
+        dist.all_to_all_single(output, input, group=group)
+        return output
+
+    @staticmethod
+    def backward(ctx: Any, grad_output: Tensor):  # type: ignore[override]
+        return None, _AllToAll.apply(ctx.group, grad_output)
+
+
+class _GateFn(torch.autograd.Function):
+    """logits, noise -> (weight [S,2], l_aux) + index tensors; HIP eve_gate_top2_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, noise: Tensor, C: int):  # type: ignore[override]
+        r = ops.gate_top2(logits.contiguous(), noise.contiguous(), C)
+        ctx.routing = r
+        outs = (r.weight, r.l_aux.view(()), r.slot, r.slot_token, r.slot_weight, r.rows, r.exp_counts, r.idx, r.loc)
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_weight, d_l_aux, *unused):  # type: ignore[override]
+        r = ctx.routing
+        if d_weight is None:
+            d_weight = torch.zeros_like(r.weight)
+        dl = None if d_l_aux is None else d_l_aux.reshape(1).float().contiguous()
+        return ops.gate_top2_bwd(r, d_weight.contiguous(), dl), None, None
+
+
+class _RouteDispatchFn(torch.autograd.Function):
+    """h -> (dispatched [E*C,M], weight [S,2], l_aux, routing tensors).
+
+    Fuses reference sharded_moe.py:350-367: modality embedding add, fp32 gate Linear,
+    top-2 gating and the dispatch einsum.  The backward produces dh once (dispatch gather
+    + gate-Linear input gradient), dwg and the two modality-embedding gradients."""
+
+    @staticmethod
+    def forward(ctx, h, wg, vemb, temb, noise, n_vis, mode, cap_factor, min_capacity):  # type: ignore[override]
+        B, T, M = h.shape
+        S = B * T
+        h2d = h.contiguous().view(S, M)
+        wg32 = wg.float().contiguous()
+        ve = None if vemb is None else vemb.to(h.dtype).contiguous()
+        te = None if temb is None else temb.to(h.dtype).contiguous()
+        E = wg32.shape[0]
+        logits = ops.gate_logits(h2d, ve, te, wg32, T, n_vis, mode)
+        C = ops.capacity(S, E, cap_factor, min_capacity)
+        r = ops.gate_top2(logits, noise.contiguous(), C)
+        xd = ops.dispatch_fwd(h2d, ve, te, r.slot_token, T, n_vis, mode)
+        ctx.routing, ctx.dims = r, (B, T, M, n_vis, mode)
+        ctx.save_for_backward(h2d, wg32, ve, te)
+        ctx.param_dtypes = (wg.dtype, None if vemb is None else vemb.dtype, None if temb is None else temb.dtype)
+        outs = (xd, r.weight, r.l_aux.view(()), r.slot, r.slot_token, r.slot_weight, r.rows, r.exp_counts)
+        ctx.mark_non_differentiable(*outs[3:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, dxd, d_weight, d_l_aux, *unused):  # type: ignore[override]
+        r = ctx.routing
+        B, T, M, n_vis, mode = ctx.dims
+        h2d, wg32, ve, te = ctx.saved_tensors
+        S = B * T
+        if d_weight is None:
+            d_weight = torch.zeros_like(r.weight)
+        dl = None if d_l_aux is None else d_l_aux.reshape(1).float().contiguous()
+        dlogits = ops.gate_top2_bwd(r, d_weight.contiguous(), dl)
+        if dxd is None:
+            dxd = torch.zeros(r.E * r.C, M, dtype=h2d.dtype, device=h2d.device)
+        dh = ops.dispatch_bwd(dxd.contiguous(), r.slot, dlogits, wg32, S)
+        wg_dt, v_dt, t_dt = ctx.param_dtypes
+        dwg = ops.gate_wgrad(h2d, ve, te, dlogits, T, n_vis, mode).to(wg_dt) if ctx.needs_input_grad[1] else None
+        dv = dt = None
+        if mode != _lib.MODE_NONE and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            want_v = ctx.needs_input_grad[2] and mode in (_lib.MODE_VL, _lib.MODE_VISION)
+            want_t = ctx.needs_input_grad[3] and mode in (_lib.MODE_VL, _lib.MODE_TEXT)
+            dv, dt = ops.embed_grad(dh, T, n_vis, mode, want_v, want_t)
+            dv = None if dv is None else dv.to(v_dt)
+            dt = None if dt is None else dt.to(t_dt)
+        return dh.view(B, T, M), dwg, dv, dt, None, None, None, None, None
+
+
+class _CombineFn(torch.autograd.Function):
+    """out[s] = w1*y[slot1] + w2*y[slot2]  (reference einsum 'sec,ecm->sm', sharded_moe.py:377)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, slot, slot_token, slot_weight):  # type: ignore[override]
+        y = y.contiguous()
+        ctx.save_for_backward(y, slot, slot_token, slot_weight)
+        return ops.combine_fwd(y, slot, weight.contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):  # type: ignore[override]
+        y, slot, slot_token, slot_weight = ctx.saved_tensors
+        dy, dw = ops.combine_bwd(dout.contiguous(), y, slot, slot_token, slot_weight)
+        return dy, dw, None, None, None
+
+
+# -------------------------------------------------------------------------- functional
+def top2gating(logits: Tensor, capacity_factor: float, min_capacity: int,
+               noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Reference-compatible top-2 gating (sharded_moe.py:172-235): returns
+    (l_aux, combine_weights [S,E,C], dispatch_mask [S,E,C], exp_counts [E] int64 on CPU).
+
+    Routing itself is computed by the fused HIP gate kernel; the dense tensors are only
+    materialised here, by one scatter, for callers that still want them.  `MOELayer` never
+    builds them.  `noise` overrides the Gumbel draw of :186 (tests)."""
+    S, E = logits.shape
+    logits = logits.float()
+    if noise is None:
+        noise = gumbel_rsample(logits.shape, device=logits.device)
+    C = ops.capacity(S, E, capacity_factor, min_capacity)
+    weight, l_aux, slot, _, _, _, exp_counts, _, _ = _GateFn.apply(logits, noise, C)
+    keep = slot >= 0
+    combine = torch.zeros(S, E * C, dtype=torch.float32, device=logits.device)
+    combine = combine.scatter(1, slot.clamp(min=0).long(), weight * keep)
+    combine = combine.view(S, E, C)
+    return l_aux, combine, combine.bool(), exp_counts.to("cpu")
+
+
+class TopKGate(nn.Module):
+    """Gate module, constructor and attributes as the reference's (sharded_moe.py:238-297).
+    `k` is validated but, as in the reference (:294), gating is always top-2."""
+
+    wg: nn.Linear
+
+    def __init__(self, model_dim: int, num_experts: int, k: int = 1, capacity_factor: float = 1.0,
+                 eval_capacity_factor: float = 1.0, min_capacity: int = 8, noisy_gate_policy: Optional[str] = None,
+                 drop_tokens: bool = True, use_rts: bool = True) -> None:
+        super().__init__()
+        if k != 1 and k != 2:
+            raise ValueError('Only top-1 and top-2 gatings are supported.')
+        self.wg = nn.Linear(model_dim, num_experts, bias=False).float()
+        self.k = k
+        self.model_dim = model_dim
+        self.num_experts = num_experts
+        self.capacity_factor = capacity_factor
+        self.eval_capacity_factor = eval_capacity_factor
+        self.min_capacity = min_capacity
+        self.noisy_gate_policy = noisy_gate_policy
+        self.wall_clock_breakdown = False
+        self.gate_time = 0.0
+        self.drop_tokens = drop_tokens
+        self.use_rts = use_rts
+
+    def active_capacity_factor(self) -> float:
+        return self.capacity_factor if self.training else self.eval_capacity_factor
+
+    def forward(self, input: Tensor, noise: Optional[Tensor] = None):
+        """[S,M] -> (l_aux, combine_weights, dispatch_mask, exp_counts), reference :283-297."""
+        if self.wg.weight.dtype != torch.float32:
+            self.wg = self.wg.float()
+        x = input
+        if self.noisy_gate_policy == 'Jitter' and self.training:
+            x = multiplicative_jitter(x.float(), device=x.device)
+        x = x.contiguous()
+        logits = _LogitsFn.apply(x, self.wg.weight)
+        return top2gating(logits, self.active_capacity_factor(), self.min_capacity, noise=noise)
+
+
+class _LogitsFn(torch.autograd.Function):
+    """x [S,M] -> fp32 logits [S,E] with the HIP gate-logits kernel (no modality add)."""
+
+    @staticmethod
+    def forward(ctx, x, wg):  # type: ignore[override]
+        wg32 = wg.float().contiguous()
+        ctx.save_for_backward(x, wg32)
+        ctx.wg_dtype = wg.dtype
+        return ops.gate_logits(x, None, None, wg32, 1, 0, _lib.MODE_NONE)
+
+    @staticmethod
+    def backward(ctx, dlogits):  # type: ignore[override]
+        x, wg32 = ctx.saved_tensors
+        dlogits = dlogits.contiguous()
+        S, M = x.shape
+        no_slots = torch.full((S, 2), -1, dtype=torch.int32, device=x.device)
+        dx = ops.dispatch_bwd(torch.zeros(1, M, dtype=x.dtype, device=x.device), no_slots, dlogits, wg32, S)
+        dwg = ops.gate_wgrad(x, None, None, dlogits, 1, 0, _lib.MODE_NONE).to(ctx.wg_dtype)
+        return dx, dwg
+
+
+uniform_map: Dict[torch.device, Callable] = {}
+
+
+def multiplicative_jitter(x: Tensor, device: torch.device, epsilon: float = 1e-2) -> Tensor:
+    """x * U(1-eps, 1+eps) (reference sharded_moe.py:46-67; only with noisy_gate_policy='Jitter',
+    which EVE never sets)."""
+    if epsilon == 0:
+        return x
+    device = torch.device(device)
+    uniform = uniform_map.get(device)
+    if uniform is None:
+        uniform = torch.distributions.uniform.Uniform(low=torch.tensor(1.0 - epsilon, device=device),
+                                                      high=torch.tensor(1.0 + epsilon, device=device)).rsample
+        uniform_map[device] = uniform
+    return x * uniform(x.shape)
+
+
+class MOELayer(nn.Module):
+    """Modality-aware MoE layer with the reference's constructor, attributes and forward
+    contract (sharded_moe.py:300-381): `forward(h, mode='vl')` returns the combined output
+    and leaves `l_aux` / `exp_counts` on the module."""
+
+    def __init__(self, gate: nn.Module, experts: nn.Module, ep_group_name, ep_size, num_local_experts: int,
+                 num_tokens=None) -> None:
+        super().__init__()
+        self.gate = gate
+        self.experts = experts
+        self.ep_group = None
+        self.ep_size = ep_size
+        self.ep_group_name = ep_group_name
+        self.num_local_experts = num_local_experts
+        self.time_falltoall = 0.0
+        self.time_salltoall = 0.0
+        self.time_moe = 0.0
+        self.wall_clock_breakdown = False
+        # exp_counts is handed back as a CPU int64 tensor like the reference's (:199).  By
+        # default the device->host copy is asynchronous (pinned buffer): the values are valid
+        # once the stream has been synchronised.  Set True for the reference's blocking copy.
+        self.blocking_exp_counts = False
+        self.l_aux = None
+        self.exp_counts = None
+        self.noise_override: Optional[Tensor] = None  # tests: replaces the Gumbel draw once
+
+        self.num_vision_tokens = None
+        if num_tokens:
+            self.vision_embed = nn.Parameter(torch.zeros(self.gate.model_dim))
+            trunc_normal_(self.vision_embed, std=0.02)
+            self.text_embed = nn.Parameter(torch.zeros(self.gate.model_dim))
+            trunc_normal_(self.text_embed, std=0.02)
+            self.num_vision_tokens = num_tokens
+
+    def _set_ep_group(self, ep_group) -> None:
+        self.ep_group = ep_group
+
+    def _resolve_ep_group(self):
+        if self.ep_size == 1:
+            return None
+        if self.ep_group is None:
+            if not dist.is_initialized():
+                raise RuntimeError("eve_amd.MOELayer: ep_size > 1 needs torch.distributed to be initialised")
+            if dist.get_world_size() != self.ep_size:
+                raise RuntimeError("eve_amd.MOELayer: ep_size != world size; pass the expert-parallel process group "
+                                   "with MOELayer._set_ep_group(group)")
+            self.ep_group = dist.group.WORLD
+        return self.ep_group
+
+    def forward(self, *input: Tensor, mode='vl', **kwargs: Any) -> Tensor:
+        h = input[0]
+        if not h.is_cuda:
+            raise RuntimeError("eve_amd.MOELayer runs on MI355X only (input is on %s); no CPU fallback" % h.device)
+        orig_shape = h.shape
+        d_model = h.shape[-1]
+        if h.dim() == 2:
+            h = h.unsqueeze(0)
+        elif h.dim() > 3:
+            h = h.reshape(-1, h.shape[-2], d_model)
+        B, T, M = h.shape
+        S = B * T
+        gate = self.gate
+        if gate.wg.weight.dtype != torch.float32:
+            gate.wg = gate.wg.float()
+        has_embed = bool(self.num_vision_tokens)
+        code = _mode_code(mode, has_embed)
+        vemb = self.vision_embed if has_embed and code in (_lib.MODE_VL, _lib.MODE_VISION) else None
+        temb = self.text_embed if has_embed and code in (_lib.MODE_VL, _lib.MODE_TEXT) else None
+        if has_embed:  # kernels want both pointers; the unused one is never read
+            vemb_in = self.vision_embed if vemb is not None else self.text_embed.detach()
+            temb_in = self.text_embed if temb is not None else self.vision_embed.detach()
+        else:
+            vemb_in = temb_in = None
+        E = gate.num_experts if hasattr(gate, "num_experts") else gate.wg.weight.shape[0]
+        noise = self.noise_override
+        self.noise_override = None
+        if noise is None:
+            noise = gumbel_rsample((S, E), device=h.device)
+        if gate.noisy_gate_policy == 'Jitter' and self.training:
+            raise NotImplementedError("eve_amd.MOELayer: noisy_gate_policy='Jitter' is not used by EVE and is only "
+                                      "supported through TopKGate.forward")
+        n_vis = int(self.num_vision_tokens) if has_embed else 0
+
+        xd, weight, l_aux, slot, slot_token, slot_weight, rows, exp_counts = _RouteDispatchFn.apply(
+            h, gate.wg.weight, vemb_in, temb_in, noise, n_vis, code, gate.active_capacity_factor(), gate.min_capacity)
+        self.l_aux = l_aux
+        self.exp_counts = _host_counts(exp_counts, self.blocking_exp_counts)
+        C = xd.shape[0] // E
+
+        group = self._resolve_ep_group()
+        if group is not None:
+            xd = _AllToAll.apply(group, xd.view(self.ep_size, -1)).view(-1, M)
+            rows = None  # peers' fill counts are not exchanged: every capacity row is processed
+        # [ep, E_local, C, M] as in the reference (:370)
+        dispatched = xd.view(self.ep_size, self.num_local_experts, C, M)
+        expert_output = self.experts(dispatched, rows=rows) if _accepts_rows(self.experts) else self.experts(dispatched)
+        expert_output = expert_output.reshape(self.ep_size * self.num_local_experts * C, M)
+        if group is not None:
+            expert_output = _AllToAll.apply(group, expert_output.view(self.ep_size, -1)).view(-1, M)
+        out = _CombineFn.apply(expert_output, weight, slot, slot_token, slot_weight)
+        return out.view(orig_shape)
+
+
+def _accepts_rows(experts: nn.Module) -> bool:
+    return getattr(experts, "accepts_rows", False)
+
+
+def _host_counts(exp_counts: Tensor, blocking: bool) -> Tensor:
+    if blocking:
+        return exp_counts.to("cpu")
+    host = torch.empty(exp_counts.shape, dtype=exp_counts.dtype, pin_memory=True)
+    host.copy_(exp_counts, non_blocking=True)
+    return host

@@ -1,0 +1,167 @@
+/* eve_moe.h -- C ABI of libeve_moe.so: MI355X (gfx950) kernels for EVE's modality-aware
+ * Mixture-of-Experts layer.
+ *
+ * The reference (ssyze/EVE) has no FFI for this path: the whole layer is stock PyTorch
+ * ops composed in models/sharded_moe.py, models/experts.py and
+ * models/multiway_transformer.py.  Each entry point below replaces one such composition;
+ * the comment on it cites the reference lines it stands in for (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory the caller owns and keeps alive until
+ *     the stream has passed the call (borrowed, never freed or retained here);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
+ *     enqueues work on it: no hipMalloc/hipFree, no host synchronisation;
+ *   - return value 0 = success, negative = EVE_ERR_*; eve_moe_last_error() gives the
+ *     message of the calling thread's most recent failure;
+ *   - `dtype` is EVE_F32 or EVE_BF16 and names the element type of activations and
+ *     expert weights; gate tensors (logits, gates, wg, noise, weights) are always fp32;
+ *   - token order is the row-major (batch, position) flattening of [B,T,M] -> [S,M];
+ *   - a "slot" is a row e*C + c of the expert-major capacity buffer [E, C, M].
+ */
+#ifndef EVE_MOE_H_
+#define EVE_MOE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVE_MOE_ABI_VERSION 1
+
+enum { EVE_F32 = 0, EVE_BF16 = 1 };
+
+/* modality routing of MOELayer.forward, models/sharded_moe.py:350-364 */
+enum {
+  EVE_MODE_NONE = 0,   /* num_tokens=None: no modality embedding            (:360-364) */
+  EVE_MODE_VL = 1,     /* positions [0,n_vis) + vision_embed, rest + text   (:355-358) */
+  EVE_MODE_VISION = 2, /* every token + vision_embed                        (:351-352) */
+  EVE_MODE_TEXT = 3    /* every token + text_embed                          (:353-354) */
+};
+
+/* expert activation, models/multiway_transformer.py:47 (ACT2FN[hidden_act]) */
+enum { EVE_ACT_QUICK_GELU = 0, EVE_ACT_GELU = 1, EVE_ACT_RELU = 2, EVE_ACT_IDENTITY = 3 };
+
+enum {
+  EVE_OK = 0,
+  EVE_ERR_ARG = -1,       /* bad shape / dtype / null pointer / misalignment */
+  EVE_ERR_WORKSPACE = -2, /* workspace too small */
+  EVE_ERR_LAUNCH = -3,    /* HIP launch error */
+  EVE_ERR_UNSUPPORTED = -4
+};
+
+int eve_moe_abi_version(void);
+const char* eve_moe_last_error(void);
+
+/* Capacity of one expert queue: max(ceil_f32(f32(S/E) * f32(2*capacity_factor)), min_capacity).
+ * Host-only arithmetic.  Replaces _capacity, models/sharded_moe.py:150-160 as called at :177. */
+int eve_capacity(int S, int E, double capacity_factor, int min_capacity);
+
+/* ---------------------------------------------------------------------------- gate */
+
+/* logits[s,e] = sum_m f32(x[s,m]) * wg[e,m],  x[s,:] = round_dtype(h[s,:] + embed(s)).
+ * Replaces the modality add (models/sharded_moe.py:350-359) feeding TopKGate.forward's
+ * `self.wg(input.float())` (:286-292).  vision_embed/text_embed have h's dtype and may be
+ * NULL when mode == EVE_MODE_NONE.  M % 8 == 0. */
+int eve_gate_logits_fwd(const void* h, const void* vision_embed, const void* text_embed, const float* wg,
+                        float* logits, int S, int T, int n_vis, int mode, int M, int E, int dtype, void* stream);
+
+/* Bytes of scratch eve_gate_top2_fwd needs for S tokens and E experts. */
+size_t eve_gate_workspace_bytes(int S, int E);
+
+/* Fused top-2 gating.  Replaces top2gating, models/sharded_moe.py:172-235, with `noise`
+ * standing in for the Gumbel draw of :186, producing index-form routing instead of the
+ * dense [S,E,C] combine_weights / dispatch_mask:
+ *   gates      [S,E]  softmax(logits)                                             (:175)
+ *   idx        [S,2]  first / second expert of each token                    (:180,:189)
+ *   loc        [S,2]  position in that expert's queue, BEFORE the capacity test (:193-196)
+ *   slot       [S,2]  idx*C+loc where the token is dispatched (loc < C and weight != 0),
+ *                     else -1                                              (:207-208,:233)
+ *   weight     [S,2]  combine weights renormalised after drops (0 if dropped) (:217-223)
+ *   slot_token [E*C]  inverse map: token held by each slot, -1 if empty
+ *   slot_weight[E*C]  that token's combine weight for the slot
+ *   exp_counts [E]    int64 first-choice counts before drops                      (:199)
+ *   rows       [E]    min(C, first + second choices): slots [0,rows) of expert e are the
+ *                     only ones that can be occupied
+ *   l_aux      [1]    load-balance loss                                       (:202-204)
+ * Routing indices and drops are bit-exact w.r.t. the reference for identical
+ * (logits, noise); fp outputs agree to fp32 rounding.  Deterministic (no atomics). */
+int eve_gate_top2_fwd(const float* logits, const float* noise, int S, int E, int C, float* gates, int32_t* idx,
+                      int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token, float* slot_weight,
+                      int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* Backward of eve_gate_top2_fwd w.r.t. logits (what autograd derives for :172-235):
+ * d_weight [S,2] and d_l_aux [1] (device scalar) in, dlogits [S,E] out. */
+int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const int32_t* loc, const float* d_weight,
+                      const float* d_l_aux, const int64_t* exp_counts, int S, int E, int C, float* dlogits,
+                      void* stream);
+
+/* dwg[e,m] = sum_s dlogits[s,e] * f32(x[s,m]) (x as in eve_gate_logits_fwd): weight gradient
+ * of TopKGate.wg, models/sharded_moe.py:271,:292.  workspace: eve_gate_wgrad_workspace_bytes. */
+size_t eve_gate_wgrad_workspace_bytes(int S, int M, int E);
+int eve_gate_wgrad(const void* h, const void* vision_embed, const void* text_embed, const float* dlogits, float* dwg,
+                   int S, int T, int n_vis, int mode, int M, int E, int dtype, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ dispatch / combine */
+
+/* xd[slot,:] = round_dtype(h[tok,:] + embed(tok)) for tok = slot_token[slot] >= 0, else 0.
+ * Replaces the modality add plus einsum("sec,sm->ecm", dispatch_mask, reshaped_input),
+ * models/sharded_moe.py:350-367.  Writes all E*C rows. */
+int eve_dispatch_fwd(const void* h, const void* vision_embed, const void* text_embed, const int32_t* slot_token,
+                     void* xd, int S, int T, int n_vis, int mode, int M, int num_slots, int dtype, void* stream);
+
+/* dh[s,:] = dxd[slot[s,0],:] + dxd[slot[s,1],:] + sum_e dlogits[s,e] * wg[e,:]  (slots < 0 skipped;
+ * dlogits may be NULL).  Backward of :350-367 plus the input gradient of the gate's Linear (:292). */
+int eve_dispatch_bwd(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh, int S,
+                     int M, int E, int dtype, void* stream);
+
+/* dvision[m] = sum over vision tokens of dh[s,m]; dtext likewise (fp32 outputs; either may
+ * be NULL).  Gradient of MOELayer.vision_embed / text_embed, models/sharded_moe.py:339-342. */
+size_t eve_embed_grad_workspace_bytes(int S, int M);
+int eve_embed_grad(const void* dh, float* dvision, float* dtext, int S, int T, int n_vis, int mode, int M, int dtype,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[s,:] = weight[s,0]*y[slot[s,0],:] + weight[s,1]*y[slot[s,1],:]  (fp32 accumulate).
+ * Replaces einsum("sec,ecm->sm", combine_weights, expert_output), models/sharded_moe.py:377. */
+int eve_combine_fwd(const void* y, const int32_t* slot, const float* weight, void* out, int S, int M, int dtype,
+                    void* stream);
+
+/* Backward of eve_combine_fwd: dy[slot,:] = slot_weight[slot]*dout[slot_token[slot],:] (0 for
+ * empty slots; all num_slots rows written) and d_weight[s,k] = <dout[s,:], y[slot[s,k],:]>. */
+int eve_combine_bwd(const void* dout, const void* y, const int32_t* slot, const int32_t* slot_token,
+                    const float* slot_weight, void* dy, float* d_weight, int S, int M, int num_slots, int dtype,
+                    void* stream);
+
+/* ----------------------------------------------------------------------- expert FFNs */
+
+/* Grouped expert FFN forward.  `x` is [G, R, M]: G groups of R rows; group g is processed
+ * by local expert g % E_local (so both the single-GPU layout [E, C, M] and the
+ * expert-parallel layout [ep, E_local, C, M] of models/sharded_moe.py:370 are covered).
+ *   z = x @ w1[e]^T + b1[e]   [G,R,I]  (saved for backward; NULL = do not store, inference)
+ *   a = act(z)                [G,R,I]  (saved for backward)
+ *   y = a @ w2[e]^T + b2[e]   [G,R,M]
+ * w1 [E_local,I,M], b1 [E_local,I], w2 [E_local,M,I], b2 [E_local,M] in `dtype`.
+ * rows[g] (may be NULL = R) limits the rows of group g that are computed; rows beyond it
+ * are left untouched.  Replaces Experts.forward (models/experts.py:18-28) over
+ * MultiwayTransformerMLP.forward (models/multiway_transformer.py:51-55). */
+int eve_ffn_fwd(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* z, void* a,
+                void* y, const int32_t* rows, int G, int E_local, int R, int M, int I, int act, int dtype,
+                void* stream);
+
+/* Grouped expert FFN backward.  In: dy [G,R,M] and the tensors of the forward.  Out:
+ *   dz  [G,R,I]  scratch (gradient at the pre-activation), dx [G,R,M],
+ *   dw1 [E_local,I,M], db1 [E_local,I], dw2 [E_local,M,I], db2 [E_local,M]  (overwritten,
+ *   summed over the groups that share an expert; `dtype` elements, fp32 accumulation).
+ * Rows >= rows[g] contribute nothing and their dx/dz rows are left untouched. */
+int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2,
+                void* dz, void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G,
+                int E_local, int R, int M, int I, int act, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVE_MOE_H_ */

@@ -1,0 +1,134 @@
+"""HIP permute (dispatch / combine) and grouped-FFN kernels vs plain torch CPU arithmetic."""
+import pytest
+import torch
+
+from oracle import moe_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float32: dict(rtol=1e-5, atol=1e-5), torch.bfloat16: dict(rtol=2e-2, atol=2e-2)}
+
+
+def _routing(S, E, seed, cf=1.0):
+    from eve_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(S, E, generator=g)
+    noise = orc.gumbel_noise((S, E), generator=g)
+    C = ops.capacity(S, E, cf, 4)
+    return ops.gate_top2(logits.to(DEV), noise.to(DEV), C), C
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,n_vis,M,E,mode", [(4, 9, 5, 64, 8, "vl"), (8, 237, 197, 768, 32, "vl"),
+                                               (3, 40, 7, 1024, 32, "text"), (6, 11, 4, 96, 4, "none")])
+def test_dispatch_and_combine_roundtrip(dtype, B, T, n_vis, M, E, mode):
+    from eve_amd import ops
+    S = B * T
+    r, C = _routing(S, E, seed=S + M, cf=0.75)
+    g = torch.Generator().manual_seed(1)
+    h = torch.randn(B, T, M, generator=g).to(dtype)
+    p = {"vision_embed": (torch.randn(M, generator=g) * 0.1).to(dtype), "text_embed": (torch.randn(M, generator=g) * 0.1).to(dtype)}
+    x = orc.modality_input(h, p, mode, n_vis if mode != "none" else None)          # [S,M] oracle
+    ve = p["vision_embed"].to(DEV) if mode != "none" else None
+    te = p["text_embed"].to(DEV) if mode != "none" else None
+    xd = ops.dispatch_fwd(h.reshape(S, M).to(DEV), ve, te, r.slot_token, T, n_vis, ops.MODES[mode]).cpu()
+    st = r.slot_token.cpu().long()
+    ref = torch.zeros(E * C, M, dtype=dtype)
+    ref[st >= 0] = x[st[st >= 0]]
+    assert torch.equal(xd, ref), "dispatch must be an exact row gather"
+
+    # combine forward / backward against dense arithmetic in fp64
+    y = torch.randn(E * C, M, generator=g).to(dtype)
+    slot, w = r.slot.cpu().long(), r.weight.cpu()
+    out = ops.combine_fwd(y.to(DEV), r.slot, r.weight).cpu()
+    yd = y.double()
+    ref_out = torch.zeros(S, M, dtype=torch.float64)
+    for k in range(2):
+        m = slot[:, k] >= 0
+        ref_out[m] += w[m, k, None].double() * yd[slot[m, k]]
+    torch.testing.assert_close(out.double(), ref_out, **TOL[dtype])
+
+    dout = torch.randn(S, M, generator=g).to(dtype)
+    dy, dw = ops.combine_bwd(dout.to(DEV), y.to(DEV), r.slot, r.slot_token, r.slot_weight)
+    ref_dy = torch.zeros(E * C, M, dtype=torch.float64)
+    ref_dw = torch.zeros(S, 2, dtype=torch.float64)
+    for k in range(2):
+        m = slot[:, k] >= 0
+        ref_dy[slot[m, k]] = w[m, k, None].double() * dout[m].double()
+        ref_dw[m, k] = (dout[m].double() * yd[slot[m, k]]).sum(1)
+    torch.testing.assert_close(dy.cpu().double(), ref_dy, **TOL[dtype])
+    torch.testing.assert_close(dw.cpu().double(), ref_dw, rtol=1e-4, atol=1e-3 if dtype == torch.bfloat16 else 1e-4)
+
+    # dispatch backward: gather-add of slot rows + dlogits @ wg
+    dxd = torch.randn(E * C, M, generator=g).to(dtype)
+    dlog = torch.randn(S, E, generator=g)
+    wg = torch.randn(E, M, generator=g) * 0.05
+    dh = ops.dispatch_bwd(dxd.to(DEV), r.slot, dlog.to(DEV), wg.to(DEV), S).cpu()
+    ref_dh = dlog.double() @ wg.double()
+    for k in range(2):
+        m = slot[:, k] >= 0
+        ref_dh[m] += dxd.double()[slot[m, k]]
+    torch.testing.assert_close(dh.double(), ref_dh, **TOL[dtype])
+
+    if mode != "none":
+        dv, dt = ops.embed_grad(dh.to(DEV), T, n_vis, ops.MODES[mode])
+        d3 = dh.double().view(B, T, M)
+        if mode == "vl":
+            rv, rt = d3[:, :n_vis].sum((0, 1)), d3[:, n_vis:].sum((0, 1))
+        elif mode == "vision":
+            rv, rt = d3.sum((0, 1)), torch.zeros(M, dtype=torch.float64)
+        else:
+            rv, rt = torch.zeros(M, dtype=torch.float64), d3.sum((0, 1))
+        torch.testing.assert_close(dv.cpu().double(), rv, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(dt.cpu().double(), rt, rtol=1e-4, atol=1e-3)
+
+
+def _ffn_ref(x, w1, b1, w2, b2, rows, E_l):
+    G, R, M = x.shape
+    ys = []
+    for g in range(G):
+        e = g % E_l
+        ys.append(orc.expert_ffn(x[g], w1[e], b1[e], w2[e], b2[e]))
+    return torch.stack(ys)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("G,E_l,R,M,I,use_rows", [(4, 4, 7, 32, 64, False), (8, 4, 33, 64, 128, True),
+                                                  (32, 32, 119, 768, 3072, True), (6, 2, 130, 128, 256, True),
+                                                  (1, 1, 300, 256, 512, False)])
+def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
+    from eve_amd import ops
+    g = torch.Generator().manual_seed(G * R + M)
+    x = torch.randn(G, R, M, generator=g)
+    w1 = torch.randn(E_l, I, M, generator=g) * (M ** -0.5)
+    b1 = torch.randn(E_l, I, generator=g) * 0.1
+    w2 = torch.randn(E_l, M, I, generator=g) * (I ** -0.5)
+    b2 = torch.randn(E_l, M, generator=g) * 0.1
+    dy = torch.randn(G, R, M, generator=g)
+    rows = torch.randint(0, R + 1, (G,), generator=g, dtype=torch.int32) if use_rows else None
+    if rows is not None:
+        rows[0] = R
+        rows[-1] = 0
+    cast = lambda t: t.to(dtype)
+    xs, w1s, b1s, w2s, b2s, dys = map(cast, (x, w1, b1, w2, b2, dy))
+    # reference in fp64 on the (possibly bf16-rounded) operands; rows beyond rows[g] masked out
+    mask = torch.ones(G, R, 1, dtype=torch.float64)
+    if rows is not None:
+        mask = (torch.arange(R)[None, :, None] < rows[:, None, None]).double()
+    leaves = [t.double().requires_grad_(True) for t in (xs, w1s, b1s, w2s, b2s)]
+    yref = _ffn_ref(*leaves, rows, E_l)
+    (yref * dys.double() * mask).sum().backward()
+
+    d = lambda t: t.to(DEV) if t is not None else None
+    z, a, y = ops.ffn_fwd(d(xs), d(w1s), d(b1s), d(w2s), d(b2s), d(rows), ops.ACTS["quick_gelu"])
+    dx, dw1, db1, dw2, db2 = ops.ffn_bwd(d(dys), d(xs), z, a, d(w1s), d(w2s), d(rows), ops.ACTS["quick_gelu"])
+    torch.cuda.synchronize()
+    m3 = mask.bool().expand(G, R, M)
+    tol = TOL[dtype]
+    torch.testing.assert_close(y.cpu().double()[m3], yref.detach()[m3], **tol)
+    torch.testing.assert_close(dx.cpu().double()[m3], leaves[0].grad[m3], **tol)
+    for got, ref, name in ((dw1, leaves[1].grad, "dw1"), (db1, leaves[2].grad, "db1"), (dw2, leaves[3].grad, "dw2"),
+                           (db2, leaves[4].grad, "db2")):
+        scale = float(ref.abs().max().clamp(min=1e-6))
+        err = float((got.cpu().double() - ref).abs().max()) / scale
+        assert err < (2e-2 if dtype == torch.bfloat16 else 2e-5), (name, err)
