@@ -46,6 +46,40 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Profile:
+    """Optional HIP-event timing of every C-ABI call, recorded on the stream the kernels are
+    launched on (bench.py uses it for the per-kernel roofline numbers).  Off by default."""
+
+    def __init__(self):
+        self.on = False
+        self._ev = []
+
+    def enable(self):
+        self.on, self._ev = True, []
+
+    def disable(self):
+        self.on = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self._ev:
+            ms, n = out.get(name, (0.0, 0))
+            out[name] = (ms + a.elapsed_time(b), n + 1)
+        self._ev = []
+        return out
+
+    def call(self, name, *args):
+        if not self.on:
+            return _lib.call(name, *args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call(name, *args)
+        b.record()
+        self._ev.append((name, a, b))
+
+
+PROFILE = _Profile()
+
+
 def capacity(S: int, E: int, capacity_factor: float, min_capacity: int) -> int:
     """models/sharded_moe.py:150-160,:177 (host arithmetic inside the library)."""
     return int(_lib.load().eve_capacity(int(S), int(E), float(capacity_factor), int(min_capacity)))
@@ -76,7 +110,7 @@ def gate_logits(h2d: torch.Tensor, vemb, temb, wg: torch.Tensor, T: int, n_vis: 
     E = wg.shape[0]
     assert wg.shape[1] == M
     logits = torch.empty(S, E, dtype=torch.float32, device=h2d.device)
-    _lib.call("eve_gate_logits_fwd", _p(h2d), _p(vemb), _p(temb), _p(wg), _p(logits), S, T, n_vis, mode, M, E,
+    PROFILE.call("eve_gate_logits_fwd", _p(h2d), _p(vemb), _p(temb), _p(wg), _p(logits), S, T, n_vis, mode, M, E,
               _dt(h2d), _stream())
     return logits
 
@@ -94,7 +128,7 @@ def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int) -> Routing:
                 torch.empty(1, **f32))
     nbytes = _lib.load().eve_gate_workspace_bytes(S, E)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _lib.call("eve_gate_top2_fwd", _p(logits), _p(noise), S, E, C, _p(r.gates), _p(r.idx), _p(r.loc), _p(r.slot),
+    PROFILE.call("eve_gate_top2_fwd", _p(logits), _p(noise), S, E, C, _p(r.gates), _p(r.idx), _p(r.loc), _p(r.slot),
               _p(r.weight), _p(r.slot_token), _p(r.slot_weight), _p(r.exp_counts), _p(r.rows), _p(r.l_aux), _p(ws),
               nbytes, _stream())
     return r
@@ -103,7 +137,7 @@ def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int) -> Routing:
 def gate_top2_bwd(r: Routing, d_weight: torch.Tensor, d_l_aux: Optional[torch.Tensor]) -> torch.Tensor:
     _chk(d_weight, "d_weight", torch.float32), _chk(d_l_aux, "d_l_aux", torch.float32)
     dlogits = torch.empty(r.S, r.E, dtype=torch.float32, device=r.gates.device)
-    _lib.call("eve_gate_top2_bwd", _p(r.gates), _p(r.idx), _p(r.loc), _p(d_weight), _p(d_l_aux), _p(r.exp_counts),
+    PROFILE.call("eve_gate_top2_bwd", _p(r.gates), _p(r.idx), _p(r.loc), _p(d_weight), _p(d_l_aux), _p(r.exp_counts),
               r.S, r.E, r.C, _p(dlogits), _stream())
     return dlogits
 
@@ -115,7 +149,7 @@ def gate_wgrad(h2d, vemb, temb, dlogits, T: int, n_vis: int, mode: int) -> torch
     dwg = torch.empty(E, M, dtype=torch.float32, device=h2d.device)
     nbytes = _lib.load().eve_gate_wgrad_workspace_bytes(S, M, E)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=h2d.device)
-    _lib.call("eve_gate_wgrad", _p(h2d), _p(vemb), _p(temb), _p(dlogits), _p(dwg), S, T, n_vis, mode, M, E, _dt(h2d),
+    PROFILE.call("eve_gate_wgrad", _p(h2d), _p(vemb), _p(temb), _p(dlogits), _p(dwg), S, T, n_vis, mode, M, E, _dt(h2d),
               _p(ws), nbytes, _stream())
     return dwg
 
@@ -125,7 +159,7 @@ def dispatch_fwd(h2d, vemb, temb, slot_token: torch.Tensor, T: int, n_vis: int, 
     S, M = h2d.shape
     n = slot_token.numel()
     xd = torch.empty(n, M, dtype=h2d.dtype, device=h2d.device)
-    _lib.call("eve_dispatch_fwd", _p(h2d), _p(vemb), _p(temb), _p(slot_token), _p(xd), S, T, n_vis, mode, M, n,
+    PROFILE.call("eve_dispatch_fwd", _p(h2d), _p(vemb), _p(temb), _p(slot_token), _p(xd), S, T, n_vis, mode, M, n,
               _dt(h2d), _stream())
     return xd
 
@@ -136,7 +170,7 @@ def dispatch_bwd(dxd: torch.Tensor, slot: torch.Tensor, dlogits, wg, S: int) -> 
     M = dxd.shape[-1]
     E = wg.shape[0] if wg is not None else 1
     dh = torch.empty(S, M, dtype=dxd.dtype, device=dxd.device)
-    _lib.call("eve_dispatch_bwd", _p(dxd), _p(slot), _p(dlogits), _p(wg), _p(dh), S, M, E, _dt(dxd), _stream())
+    PROFILE.call("eve_dispatch_bwd", _p(dxd), _p(slot), _p(dlogits), _p(wg), _p(dh), S, M, E, _dt(dxd), _stream())
     return dh
 
 
@@ -147,7 +181,7 @@ def embed_grad(dh: torch.Tensor, T: int, n_vis: int, mode: int, want_v=True, wan
     dt = torch.empty(M, dtype=torch.float32, device=dh.device) if want_t else None
     nbytes = _lib.load().eve_embed_grad_workspace_bytes(S, M)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dh.device)
-    _lib.call("eve_embed_grad", _p(dh), _p(dv), _p(dt), S, T, n_vis, mode, M, _dt(dh), _p(ws), nbytes, _stream())
+    PROFILE.call("eve_embed_grad", _p(dh), _p(dv), _p(dt), S, T, n_vis, mode, M, _dt(dh), _p(ws), nbytes, _stream())
     return dv, dt
 
 
@@ -156,7 +190,7 @@ def combine_fwd(y: torch.Tensor, slot: torch.Tensor, weight: torch.Tensor) -> to
     S = slot.shape[0]
     M = y.shape[-1]
     out = torch.empty(S, M, dtype=y.dtype, device=y.device)
-    _lib.call("eve_combine_fwd", _p(y), _p(slot), _p(weight), _p(out), S, M, _dt(y), _stream())
+    PROFILE.call("eve_combine_fwd", _p(y), _p(slot), _p(weight), _p(out), S, M, _dt(y), _stream())
     return out
 
 
@@ -166,7 +200,7 @@ def combine_bwd(dout: torch.Tensor, y: torch.Tensor, slot, slot_token, slot_weig
     n = slot_token.numel()
     dy = torch.empty(n, M, dtype=y.dtype, device=y.device)
     dw = torch.empty(S, 2, dtype=torch.float32, device=y.device)
-    _lib.call("eve_combine_bwd", _p(dout), _p(y), _p(slot), _p(slot_token), _p(slot_weight), _p(dy), _p(dw), S, M, n,
+    PROFILE.call("eve_combine_bwd", _p(dout), _p(y), _p(slot), _p(slot_token), _p(slot_weight), _p(dy), _p(dw), S, M, n,
               _dt(y), _stream())
     return dy, dw
 
@@ -182,7 +216,7 @@ def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True):
     z = torch.empty(G, R, I, dtype=x.dtype, device=x.device) if save_z else None
     a = torch.empty(G, R, I, dtype=x.dtype, device=x.device)
     y = torch.empty(G, R, M, dtype=x.dtype, device=x.device)
-    _lib.call("eve_ffn_fwd", _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(z), _p(a), _p(y), _p(rows), G, E_l, R, M, I,
+    PROFILE.call("eve_ffn_fwd", _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(z), _p(a), _p(y), _p(rows), G, E_l, R, M, I,
               act, _dt(x), _stream())
     return z, a, y
 
@@ -195,12 +229,11 @@ def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int):
     E_l, I, _ = w1.shape
     dev = x.device
     dz = torch.empty(G, R, I, dtype=x.dtype, device=dev)
-    # rows beyond rows[g] are never written by the kernels; zero so EP exchanges carry zeros
-    dx = torch.zeros(G, R, M, dtype=x.dtype, device=dev) if rows is not None else torch.empty(G, R, M, dtype=x.dtype, device=dev)
+    dx = torch.empty(G, R, M, dtype=x.dtype, device=dev)  # rows >= rows[g] stay unwritten and are never read
     dw1 = torch.empty(E_l, I, M, dtype=x.dtype, device=dev)
     db1 = torch.empty(E_l, I, dtype=x.dtype, device=dev)
     dw2 = torch.empty(E_l, M, I, dtype=x.dtype, device=dev)
     db2 = torch.empty(E_l, M, dtype=x.dtype, device=dev)
-    _lib.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),
+    PROFILE.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),
               _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _stream())
     return dx, dw1, db1, dw2, db2

@@ -347,6 +347,7 @@ class MOELayer(nn.Module):
             h, gate.wg.weight, vemb_in, temb_in, noise, n_vis, code, gate.active_capacity_factor(), gate.min_capacity)
         self.l_aux = l_aux
         self.exp_counts = _host_counts(exp_counts, self.blocking_exp_counts)
+        self.last_slot = slot  # [S,2] int32 token -> slot map of the latest forward (diagnostics)
         C = xd.shape[0] // E
 
         group = self._resolve_ep_group()

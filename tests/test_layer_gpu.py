@@ -79,14 +79,19 @@ def test_cfg1_full_shape_fp32_vs_reference(layer_cfg1):
     np.testing.assert_allclose(l_aux.item(), z["l_aux"], rtol=1e-5)
     dh = hd.grad.cpu().reshape(B * T, M)
     np.testing.assert_allclose(dh[tok].numpy(), z["dh_slice"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(moe.moe.gate.wg.weight.grad.cpu().numpy(), z["dwg"], rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(moe.moe.vision_embed.grad.cpu().numpy(), z["dvision_embed"], rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(moe.moe.text_embed.grad.cpu().numpy(), z["dtext_embed"], rtol=1e-3, atol=1e-4)
+    # reductions over ~1.9k tokens: compare against the tensor's scale (fp32 tolerance 1e-5, BASELINE.json)
+    def close(got, ref, tol=1e-5):
+        ref = torch.from_numpy(np.asarray(ref))
+        assert rel_err(torch.as_tensor(got), ref) < tol
+
+    close(moe.moe.gate.wg.weight.grad.cpu(), z["dwg"])
+    close(moe.moe.vision_embed.grad.cpu(), z["dvision_embed"])
+    close(moe.moe.text_embed.grad.cpu(), z["dtext_embed"])
     dw1, db1, dw2, db2 = expert_grads(moe, E)
-    np.testing.assert_allclose(db1.numpy(), z["db1"], rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(db2.numpy(), z["db2"], rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(dw1[3, ::97].numpy(), z["dw1_e3_rows"], rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(dw2[3, ::31].numpy(), z["dw2_e3_rows"], rtol=1e-3, atol=1e-5)
+    close(db1, z["db1"])
+    close(db2, z["db2"])
+    close(dw1[3, ::97], z["dw1_e3_rows"])
+    close(dw2[3, ::31], z["dw2_e3_rows"])
     np.testing.assert_allclose(dw1.double().abs().sum((1, 2)).numpy(), z["dw1_abs_sum"], rtol=1e-4)
     np.testing.assert_allclose(dw2.double().abs().sum((1, 2)).numpy(), z["dw2_abs_sum"], rtol=1e-4)
 
