@@ -5,10 +5,12 @@
 namespace eve {
 
 template <bool FAST> __device__ __forceinline__ float exp_(float x) { if constexpr (FAST) return __expf(x); else return expf(x); }
+// 1/x: v_rcp_f32 (1 ulp) on the fast path, IEEE division otherwise
+template <bool FAST> __device__ __forceinline__ float rcp_(float x) { if constexpr (FAST) return __builtin_amdgcn_rcpf(x); else return 1.f / x; }
 
 template <int ACT, bool FAST> __device__ __forceinline__ float act_fwd(float z) {
   if constexpr (ACT == EVE_ACT_QUICK_GELU) {
-    return z / (1.f + exp_<FAST>(-1.702f * z));  // z * sigmoid(1.702 z)
+    return z * rcp_<FAST>(1.f + exp_<FAST>(-1.702f * z));  // z * sigmoid(1.702 z)
   } else if constexpr (ACT == EVE_ACT_GELU) {
     return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
   } else if constexpr (ACT == EVE_ACT_RELU) {
@@ -20,7 +22,7 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_fwd(float z) 
 
 template <int ACT, bool FAST> __device__ __forceinline__ float act_bwd(float z) {
   if constexpr (ACT == EVE_ACT_QUICK_GELU) {
-    const float s = 1.f / (1.f + exp_<FAST>(-1.702f * z));
+    const float s = rcp_<FAST>(1.f + exp_<FAST>(-1.702f * z));
     return s * (1.f + 1.702f * z * (1.f - s));
   } else if constexpr (ACT == EVE_ACT_GELU) {
     return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * exp_<FAST>(-0.5f * z * z);

@@ -7,13 +7,16 @@
 // "k-major" operands (the contraction index is the slow, row index in memory) are staged in
 // LDS as they lie in memory and transposed on the way to the MFMA by ds_read_b64_tr_b16.
 //
-// Block = 256 threads (4 waves, 2x2), tile 128x128x64, each wave a 64x64 output (2x2 MFMA
-// tiles of 32x32).  Global -> registers -> LDS staging with the next tile's loads in flight
-// under the current tile's MFMAs, two LDS stages, one barrier per K step.  LDS images are
-// XOR-swizzled per 16-byte chunk so that both ds_read_b128 (row-major tiles) and the
-// transposed reads (k-major tiles) are bank-conflict free.  The epilogue goes through LDS
-// (fp32) so that global stores are 16 bytes per lane along rows, and fuses bias, activation,
-// activation derivative and -- in the weight-gradient kernels -- the bias gradient.
+// Block tile BM x 128 x 64 with BM = 256 (8 waves, 4x2) or 128 (4 waves, 2x2); each wave owns a
+// 64x64 output (2x2 MFMA tiles of 32x32).  Tiles travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4), NS stages deep: NS-1 tiles are in flight while one is being
+// multiplied, waited for with a COUNTED vmcnt and a raw s_barrier so the younger DMAs stay in
+// flight across the barrier.  LDS images are XOR-swizzled per 16-byte chunk -- applied to the
+// DMA's per-lane SOURCE address, since an LDS-DMA writes lane-linear -- so that ds_read_b128
+// (row-major tiles) and the transposed reads (k-major tiles) are bank-conflict free.  The
+// epilogue goes through LDS (fp32) so that global stores are 16 bytes per lane along rows, and
+// fuses bias, activation, activation derivative and -- in the weight-gradient kernels -- the
+// bias gradient (column sums of the k-major A tile).
 #include "ffn_mfma.h"
 
 #include "act.h"
@@ -27,12 +30,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 enum { MEPI_STORE = 0, MEPI_BIAS = 1, MEPI_BIAS_ACT = 2, MEPI_DACT = 3 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB, same for both tile kinds
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
-constexpr int EPI_LD = 68;                    // floats per row of a wave's 64x64 epilogue image
-constexpr int EPI_BYTES = 4 * 64 * EPI_LD * 4;
-constexpr int LDS_BYTES = EPI_BYTES > 2 * STAGE_BYTES ? EPI_BYTES : 2 * STAGE_BYTES;
+constexpr int BN = 256, BK = 64;
+constexpr int WTM = 4, WTN = 2;  // MFMA tiles per wave: 128 x 64 outputs
+constexpr int EPI_LD = 68;       // floats per row of a wave's 32x64 epilogue image
+
+template <int BM, int NS> struct Cfg {
+  static constexpr int kWaves = (BM / 128) * (BN / 64);  // waves as (BM/128) x 4, 128x64 outputs each
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr int kATile = BM * BK * 2;              // bytes
+  static constexpr int kBTile = BN * BK * 2;
+  static constexpr int kStage = kATile + kBTile;
+  static constexpr int kEpi = kWaves * 32 * EPI_LD * 4;
+  static constexpr int kLds = NS * kStage > kEpi ? NS * kStage : kEpi;
+  static constexpr int kDmaA = kATile / 1024 / kWaves;   // DMA instructions per wave per tile
+  static constexpr int kDmaB = kBTile / 1024 / kWaves;
+};
 
 struct MfmaDesc {
   const bf16_t* A;
@@ -50,38 +62,55 @@ struct MfmaDesc {
 };
 
 // ---- LDS images -------------------------------------------------------------------
-// row-major tile: [128 rows][64 k] bf16, 128 B per row, 8 chunks of 16 B
+// row-major tile: [W rows][64 k] bf16, 128 B per row, 8 chunks of 16 B
 __device__ __forceinline__ int row_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// k-major tile: [64 k][128 cols] bf16, 256 B per row, 16 chunks of 16 B
-__device__ __forceinline__ int col_tile_off(int k, int chunk) { return k * 256 + ((chunk ^ ((k & 3) << 2)) << 4); }
+// k-major tile: [64 k][W cols] bf16, 2W B per row, W/8 chunks of 16 B
+template <int W> __device__ __forceinline__ int col_tile_off(int k, int chunk) {
+  return k * (2 * W) + ((chunk ^ ((k & 3) << 2)) << 4);
+}
 
-template <bool COL>
-__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ origin, int ld, int rows_valid, uint4 (&regs)[4]) {
-  constexpr int CPR = COL ? 16 : 8;
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins below: the host pass sees an empty kernel body
+// Direct global -> LDS copy of one tile by LDS-DMA (buffer_load_dwordx4 ... lds: 16 B per lane,
+// 1 KiB per wave instruction).  The LDS image of one instruction is lane-linear, so the chunk swizzle
+// is applied to the per-lane SOURCE offset.  Loads go through a buffer descriptor whose extent is
+// the valid part of the operand: lanes that fall outside it read zeros, which is what zero-fills
+// the rows past the end of a weight-gradient segment (and keeps every access inside the tensor).
+// voff[i] is the loop-invariant per-lane byte offset of DMA i inside a tile (tile_dma_offsets).
+template <bool COL, int W, int WAVES>
+__device__ __forceinline__ void tile_dma_offsets(int ld, int wave, int lane, uint32_t (&voff)[W * BK * 2 / 1024 / WAVES]) {
+  constexpr int PIECES = W * BK * 2 / 1024;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + 256 * i;
-    const int row = idx / CPR, c = idx % CPR;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row < rows_valid) v = *reinterpret_cast<const uint4*>(origin + (size_t)row * ld + c * 8);
-    regs[i] = v;
+  for (int i = 0; i < PIECES / WAVES; ++i) {
+    const int P = (i * WAVES + wave) * 64 + lane;
+    int row, c;
+    if constexpr (COL) {
+      constexpr int CPR = W / 8;
+      row = P / CPR;
+      c = (P % CPR) ^ ((row & 3) << 2);
+    } else {
+      row = P >> 3;
+      c = (P & 7) ^ ((row >> 1) & 7);
+    }
+    voff[i] = ((uint32_t)row * (uint32_t)ld + (uint32_t)c * 8u) * 2u;
   }
 }
 
-template <bool COL>
-__device__ __forceinline__ void tile_store(char* tile, const uint4 (&regs)[4]) {
-  constexpr int CPR = COL ? 16 : 8;
+template <int W, int WAVES>
+__device__ __forceinline__ void tile_dma(__amdgpu_buffer_rsrc_t rsrc, uint32_t origin_bytes,
+                                         const uint32_t (&voff)[W * BK * 2 / 1024 / WAVES], char* tile, int wave) {
+  constexpr int PIECES = W * BK * 2 / 1024;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + 256 * i;
-    const int row = idx / CPR, c = idx % CPR;
-    const int off = COL ? col_tile_off(row, c) : row_tile_off(row, c);
-    *reinterpret_cast<uint4*>(tile + off) = regs[i];
+  for (int i = 0; i < PIECES / WAVES; ++i) {
+    const int piece = i * WAVES + wave;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + piece * 1024), 16,
+                                             voff[i] + origin_bytes, 0, 0, 0);
   }
 }
+
+#endif  // __HIP_DEVICE_COMPILE__
 
 // Fragment of the 32-row (or 32-column) sub-tile starting at r0, K sub-step ks (16 deep).
-template <bool COL>
+template <bool COL, int W>
 __device__ __forceinline__ bf16x8 frag_load(const char* tile, int r0, int ks, int lane) {
   if constexpr (!COL) {
     const int row = r0 + (lane & 31);
@@ -96,7 +125,7 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int r0, int ks, in
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int k = ks * 16 + 8 * h + 4 * r + q;
-      const int off = col_tile_off(k, e >> 3) + ((e & 7) << 1);
+      const int off = col_tile_off<W>(k, e >> 3) + ((e & 7) << 1);
       v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) char*)(tile + off));
     }
@@ -112,31 +141,71 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   const bf16_t a = static_cast<bf16_t>(lo), b = static_cast<bf16_t>(hi);
   return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
 }
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
 
-template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD>
-__global__ __launch_bounds__(256, 2) void grouped_gemm_mfma(MfmaDesc d) {
+// wait until at most `tiles` of this wave's youngest tiles (PER DMA instructions each) are in flight
+template <int PER> __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+  if (tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+  else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+  else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int BM, int NS, bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD>
+__global__ __launch_bounds__((BM / 128) * 256) void grouped_gemm_mfma(MfmaDesc d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using C_ = Cfg<BM, NS>;
+  constexpr int D = NS - 1;  // tiles in flight ahead of the one being multiplied
+  static_assert(D >= 1 && D <= 3, "prefetch depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  const int z = blockIdx.z;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private
+  // L2), so block b and b+8 share an L2.  Every XCD walks a contiguous run of whole groups (sorted
+  // expert-major, so groups that share weights sit on one XCD) and, inside a group, all its tiles
+  // with the row tile varying fastest: the ~32 tiles an XCD runs at a time then share their A row
+  // panels and B column panels through its L2 instead of each streaming them from HBM.
+  // (Speed only: correctness does not depend on where a block runs.)
+  const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
+  const int tiles_per_group = tiles_m * tiles_n;
+  const int ngroups = WGRAD ? d.E_local : d.G;
+  const int chunk = (ngroups + 7) >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int p = xcd * chunk + local / tiles_per_group;
+  if (p >= ngroups) return;
+  const int tile = local % tiles_per_group;
+  int z;
+  if (WGRAD) {
+    z = p;
+  } else {
+    const int ep = d.G / d.E_local;
+    z = (p % ep) * d.E_local + p / ep;  // p enumerates (expert, source) pairs expert-major
+  }
+  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
 
   int mext = d.Mext;
   if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
   if (m0 >= mext) return;
 
-  f32x16 acc[2][2];
+  f32x16 acc[WTM][WTN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WTN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float bsum[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-  const bool do_bias_grad = BIAS_GRAD && blockIdx.x == 0;
+  const bool do_bias_grad = BIAS_GRAD && n0 == 0;
+
+  uint32_t voff_a[C_::kDmaA], voff_b[C_::kDmaB];
+  tile_dma_offsets<A_COL, BM, C_::kWaves>(d.lda, wave, lane, voff_a);
+  tile_dma_offsets<B_COL, BN, C_::kWaves>(d.ldb, wave, lane, voff_b);
 
   const int nseg = WGRAD ? d.G / d.E_local : 1;
   for (int seg = 0; seg < nseg; ++seg) {
@@ -148,161 +217,235 @@ __global__ __launch_bounds__(256, 2) void grouped_gemm_mfma(MfmaDesc d) {
     if (nk == 0) continue;
     const bf16_t* Ag = d.A + (size_t)g * d.a_g;
     const bf16_t* Bg = d.B + (size_t)(WGRAD ? g : e) * d.b_g;
-    // tile origin and number of valid LDS rows for K step t
-    auto a_origin = [&](int t) { return A_COL ? Ag + (size_t)(t * BK) * d.lda + m0 : Ag + (size_t)m0 * d.lda + t * BK; };
-    auto b_origin = [&](int t) { return B_COL ? Bg + (size_t)(t * BK) * d.ldb + n0 : Bg + (size_t)n0 * d.ldb + t * BK; };
-    auto a_valid = [&](int t) { return A_COL ? kext - t * BK : mext - m0; };
-    auto b_valid = [&](int t) { return B_COL ? kext - t * BK : BN; };
+    // byte offset of K tile t's origin inside the group's A / the expert's (or group's) B
+    auto a_origin = [&](int t) { return (uint32_t)(A_COL ? (t * BK) * d.lda + m0 : m0 * d.lda + t * BK) * 2u; };
+    auto b_origin = [&](int t) { return (uint32_t)(B_COL ? (t * BK) * d.ldb + n0 : n0 * d.ldb + t * BK) * 2u; };
+    // valid extent of the operands: whole [R, K] group / weight matrix, or the first kext rows of a
+    // k-major activation in the weight-gradient kernels (rows past it then read as zero)
+    const uint32_t a_bytes = (uint32_t)(A_COL ? (WGRAD ? kext : d.K) * d.lda : d.Mext * d.lda) * 2u;
+    const uint32_t b_bytes = (uint32_t)(B_COL ? (WGRAD ? kext : d.K) * d.ldb : d.N * d.ldb) * 2u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bg), 0, b_bytes, 0x00020000);
+    auto stage = [&](int t) {
+      char* sa_ = smem + (t % NS) * C_::kStage;
+      tile_dma<BM, C_::kWaves>(a_rsrc, a_origin(t), voff_a, sa_, wave_u);
+      tile_dma<BN, C_::kWaves>(b_rsrc, b_origin(t), voff_b, sa_ + C_::kATile, wave_u);
+    };
 
-    uint4 ra[4], rb[4];
-    tile_load<A_COL>(a_origin(0), d.lda, a_valid(0), ra);
-    tile_load<B_COL>(b_origin(0), d.ldb, b_valid(0), rb);
-    __syncthreads();  // previous segment's / nothing's readers are done with stage 0
-    tile_store<A_COL>(smem, ra);
-    tile_store<B_COL>(smem + TILE_BYTES, rb);
-    if (do_bias_grad) {
+    // Software pipeline over half K tiles (32 deep): while the MFMAs of one half run, the LDS reads
+    // of the next half are already in flight into the other fragment set, across the barrier too:
+    //   read H1(t) | MFMA H0(t) | wait tile t+1, barrier, DMA tile t+D, read H0(t+1) | MFMA H1(t) | ...
+    constexpr int KH = BK / 32;  // k16 steps per half
+    bf16x8 a0[KH][WTM], b0[KH][WTN];
+    bf16x8 a1[WGRAD ? 1 : KH][WGRAD ? 1 : WTM], b1[WGRAD ? 1 : KH][WGRAD ? 1 : WTN];
+    auto read_half = [&](const char* sa, bf16x8 (&fa)[KH][WTM], bf16x8 (&fb)[KH][WTN], int half) {
+      const char* sb = sa + C_::kATile;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t* w = &ra[i].x;
+      for (int ks = 0; ks < KH; ++ks) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum[j] += bf16_bits_to_f32(w[j >> 1], j & 1);
+        for (int j = 0; j < WTN; ++j) fb[ks][j] = frag_load<B_COL, BN>(sb, wn * 64 + j * 32, half * KH + ks, lane);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[ks][i] = frag_load<A_COL, BM>(sa, wm * 128 + i * 32, half * KH + ks, lane);
       }
-    }
-    __syncthreads();
-
-    for (int t = 0; t < nk; ++t) {
-      const char* sa = smem + (t & 1) * STAGE_BYTES;
-      const char* sb = sa + TILE_BYTES;
-      const bool more = t + 1 < nk;
-      if (more) {
-        tile_load<A_COL>(a_origin(t + 1), d.lda, a_valid(t + 1), ra);
-        tile_load<B_COL>(b_origin(t + 1), d.ldb, b_valid(t + 1), rb);
-      }
+    };
+    auto mfma_half = [&](const bf16x8 (&fa)[KH][WTM], const bf16x8 (&fb)[KH][WTN]) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8 af[2], bfr[2];
+      for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = frag_load<A_COL>(sa, wm * 64 + i * 32, ks, lane);
+        for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[j] = frag_load<B_COL>(sb, wn * 64 + j * 32, ks, lane);
+          for (int j = 0; j < WTN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto bias_grad_tile = [&](const char* sa) {
+      if constexpr (BIAS_GRAD) {
+        if (do_bias_grad) {  // column sums of the k-major A tile, read back from LDS
+          constexpr int CPR = BM / 8;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) {
-        char* na = smem + ((t + 1) & 1) * STAGE_BYTES;
-        tile_store<A_COL>(na, ra);
-        tile_store<B_COL>(na + TILE_BYTES, rb);
-        if (do_bias_grad) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t* w = &ra[i].x;
+          for (int i = 0; i < C_::kATile / 16 / C_::kThreads; ++i) {
+            const int idx = threadIdx.x + C_::kThreads * i;
+            const uint4 v = *reinterpret_cast<const uint4*>(sa + col_tile_off<BM>(idx / CPR, idx % CPR));
+            const uint32_t* w = &v.x;
 #pragma unroll
             for (int j = 0; j < 8; ++j) bsum[j] += bf16_bits_to_f32(w[j >> 1], j & 1);
           }
         }
       }
-      __syncthreads();
+    };
+
+    __syncthreads();  // a previous segment's readers are done with every stage
+    for (int t = 0; t < D && t < nk; ++t) stage(t);
+    wait_tiles_in_flight<C_::kDmaA + C_::kDmaB>(min(D - 1, nk - 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile 0 is in LDS
+    if (D < nk) stage(D);
+    if constexpr (!WGRAD) {
+      read_half(smem, a0, b0, 0);
+      for (int t = 0; t < nk; ++t) {
+        const char* sa = smem + (t % NS) * C_::kStage;
+        read_half(sa, a1, b1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) {
+          // tile t+1 must have landed; tiles t+2 .. t+D (where they exist) may stay in flight
+          wait_tiles_in_flight<C_::kDmaA + C_::kDmaB>(min(D - 1, nk - 2 - t));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile t are complete
+          __builtin_amdgcn_s_barrier();                       // tile t+1 visible; tile t's stage is free
+          if (t + 1 + D < nk) stage(t + 1 + D);               // into the stage tile t was read from
+          read_half(smem + ((t + 1) % NS) * C_::kStage, a0, b0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_half(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // weight-gradient kernels: transposed reads need more address registers, so one fragment
+      // set only (no register double buffering) to stay inside 256 registers
+      for (int t = 0; t < nk; ++t) {
+        const char* sa = smem + (t % NS) * C_::kStage;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          read_half(sa, a0, b0, half);
+          mfma_half(a0, b0);
+        }
+        bias_grad_tile(sa);
+        if (t + 1 < nk) {
+          wait_tiles_in_flight<C_::kDmaA + C_::kDmaB>(min(D - 1, nk - 2 - t));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (t + 1 + D < nk) stage(t + 1 + D);
+        }
+      }
     }
   }
+  __syncthreads();  // all fragment reads done before the epilogue reuses LDS
 
   // ------------------------------------------------------------------ epilogue
-  // (the K loop ended with a barrier: nobody reads the staging buffers any more)
+  // Per wave, one 32-row slab (MFMA row tile i) at a time through a private fp32 LDS image, so that
+  // global stores are 16 B per lane along rows.  Only the wave itself touches its image.
   const int e_out = WGRAD ? z : z % d.E_local;
-  float* ep = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
-  {
-    const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float bv = 0.f;
-      if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT)
-        bv = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * 32 + c]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv;
-        }
-    }
-  }
-  __syncthreads();
+  float* ep = reinterpret_cast<float*>(smem) + wave * 32 * EPI_LD;
   bf16_t* Cg = d.C ? d.C + (size_t)z * d.c_g : nullptr;
   bf16_t* C2g = d.C2 ? d.C2 + (size_t)z * d.c_g : nullptr;
   const bf16_t* Zg = d.Zin ? d.Zin + (size_t)z * d.c_g : nullptr;
+  float bv[WTN];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int item = it * 64 + lane;
-    const int row = item >> 3, ch = item & 7;
-    const int m = m0 + wm * 64 + row;
-    if (m >= mext) continue;
-    const int n = n0 + wn * 64 + ch * 8;
-    const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8);
-    const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8 + 4);
-    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    const size_t o = (size_t)m * d.ldc + n;
-    if constexpr (EPI == MEPI_BIAS_ACT) {
-      if (Cg) *reinterpret_cast<uint4*>(Cg + o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+  for (int j = 0; j < WTN; ++j) {
+    bv[j] = 0.f;
+    if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT)
+      bv[j] = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * 32 + (lane & 31)]);
+  }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
-      *reinterpret_cast<uint4*>(C2g + o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-    } else {
-      if constexpr (EPI == MEPI_DACT) {
-        const uint4 zz = *reinterpret_cast<const uint4*>(Zg + o);
-        const uint32_t* w = &zz.x;
+  for (int i = 0; i < WTM; ++i) {
+    const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
       }
-      *reinterpret_cast<uint4*>(Cg + o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item >> 3, ch = item & 7;
+      const int m = m0 + wm * 128 + i * 32 + row;
+      if (m >= mext) continue;
+      const int n = n0 + wn * 64 + ch * 8;
+      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const size_t o = (size_t)m * d.ldc + n;
+      if constexpr (EPI == MEPI_BIAS_ACT) {
+        if (Cg) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
+        *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
+      } else {
+        if constexpr (EPI == MEPI_DACT) {
+          const uint4 zz = *reinterpret_cast<const uint4*>(Zg + o);
+          const uint32_t* w = &zz.x;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
+        }
+        *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+      }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
 
   if constexpr (BIAS_GRAD) {
     if (do_bias_grad) {  // block-uniform
       __syncthreads();
-      float* red = reinterpret_cast<float*>(smem);  // [16 row groups][128 columns]
-      const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+      constexpr int CPR = BM / 8, RG = C_::kThreads / CPR;  // row groups that share a chunk column
+      float* red = reinterpret_cast<float*>(smem);           // [RG][BM]
+      const int c = threadIdx.x % CPR, rg = threadIdx.x / CPR;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) red[rg * 128 + c * 8 + j] = bsum[j];
+      for (int j = 0; j < 8; ++j) red[rg * BM + c * 8 + j] = bsum[j];
       __syncthreads();
-      if (threadIdx.x < 128) {
+      if (threadIdx.x < BM) {
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += red[r * 128 + threadIdx.x];
+        for (int r = 0; r < RG; ++r) s += red[r * BM + threadIdx.x];
         d.dbias[(size_t)z * d.Mext + m0 + threadIdx.x] = static_cast<bf16_t>(s);
       }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
-bool ffn_mfma_supported(int M, int I) { return M % 128 == 0 && I % 128 == 0; }
+bool ffn_mfma_supported(int M, int I) { return M % 256 == 0 && I % 256 == 0; }
 
-template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
-static int launch(const MfmaDesc& d, int act, hipStream_t st) {
-  dim3 grid(d.N / BN, ceil_div(d.Mext, BM), WGRAD ? d.E_local : d.G);
-#define EVE_MFMA_ACT(A)                                                                                              \
-  case A:                                                                                                            \
-    hipLaunchKernelGGL((grouped_gemm_mfma<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD>), grid, dim3(256), LDS_BYTES, st, d); \
-    break;
+template <int BM, int NS, bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
+static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
+  using C_ = Cfg<BM, NS>;
+  const int ngroups = WGRAD ? d.E_local : d.G;
+  dim3 grid(8 * ceil_div(ngroups, 8) * (d.N / BN) * ceil_div(d.Mext, BM));
+#define EVE_MFMA_LAUNCH(A)                                                                                   \
+  do {                                                                                                       \
+    auto kern = grouped_gemm_mfma<BM, NS, A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD>;                           \
+    static bool attr_done = false;                                                                           \
+    if (!attr_done) {                                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              C_::kLds) != hipSuccess) {                                                     \
+        set_error("ffn_mfma: cannot reserve %d bytes of LDS", C_::kLds);                                     \
+        return EVE_ERR_LAUNCH;                                                                               \
+      }                                                                                                      \
+      attr_done = true;                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, dim3(C_::kThreads), C_::kLds, st, d);                                     \
+  } while (0)
   if constexpr (EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT) {
     switch (act) {
-      EVE_MFMA_ACT(EVE_ACT_QUICK_GELU)
-      EVE_MFMA_ACT(EVE_ACT_GELU)
-      EVE_MFMA_ACT(EVE_ACT_RELU)
-      EVE_MFMA_ACT(EVE_ACT_IDENTITY)
+      case EVE_ACT_QUICK_GELU: EVE_MFMA_LAUNCH(EVE_ACT_QUICK_GELU); break;
+      case EVE_ACT_GELU: EVE_MFMA_LAUNCH(EVE_ACT_GELU); break;
+      case EVE_ACT_RELU: EVE_MFMA_LAUNCH(EVE_ACT_RELU); break;
+      case EVE_ACT_IDENTITY: EVE_MFMA_LAUNCH(EVE_ACT_IDENTITY); break;
       default:
         set_error("ffn_mfma: unknown activation %d", act);
         return EVE_ERR_ARG;
     }
   } else {
-    hipLaunchKernelGGL((grouped_gemm_mfma<A_COL, B_COL, EPI, EVE_ACT_IDENTITY, WGRAD, BIAS_GRAD>), grid, dim3(256),
-                       LDS_BYTES, st, d);
+    EVE_MFMA_LAUNCH(EVE_ACT_IDENTITY);
   }
-#undef EVE_MFMA_ACT
+#undef EVE_MFMA_LAUNCH
   EVE_CHECK_LAUNCH("grouped_gemm_mfma");
   return EVE_OK;
+}
+
+// Tile choice: 256 x 256 tiles (8 waves) unless the row extent is small enough that a 256-row
+// tile would be mostly padding (then 128 x 256 tiles, 4 waves).
+template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
+static int launch(const MfmaDesc& d, int act, hipStream_t st) {
+  const bool small = !WGRAD && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024));
+  if (small) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
+  return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
 }
 
 int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* z, void* a,

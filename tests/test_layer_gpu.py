@@ -101,7 +101,7 @@ def test_layer_bf16_vs_oracle(mode):
     """bf16 layer vs the fp32 oracle evaluated on the same (bf16-rounded) parameters, with the
     GPU's own logits injected so routing is identical: tolerance rtol 2e-2 (BASELINE.json)."""
     from eve_amd import ops
-    M, I, E, B, n_vis, T = 128, 256, 32, 16, 11, 20
+    M, I, E, B, n_vis, T = 256, 512, 32, 16, 11, 20
     p = {k: v.to(torch.bfloat16) for k, v in orc.make_params(M, I, E, seed=21).items()}
     p["wg"] = p["wg"].float()
     h = orc.synth_hidden(B, T, M, seed=22).to(torch.bfloat16)

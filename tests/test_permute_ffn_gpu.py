@@ -94,8 +94,9 @@ def _ffn_ref(x, w1, b1, w2, b2, rows, E_l):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("G,E_l,R,M,I,use_rows", [(4, 4, 7, 32, 64, False), (8, 4, 33, 64, 128, True),
-                                                  (32, 32, 119, 768, 3072, True), (6, 2, 130, 128, 256, True),
-                                                  (1, 1, 300, 256, 512, False)])
+                                                  (32, 32, 119, 768, 3072, True), (6, 2, 130, 256, 512, True),
+                                                  (1, 1, 300, 256, 512, False), (4, 2, 700, 256, 256, True),
+                                                  (2, 2, 1024, 512, 256, False), (8, 4, 474, 256, 768, True)])
 def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
     from eve_amd import ops
     g = torch.Generator().manual_seed(G * R + M)
