@@ -1,0 +1,115 @@
+"""Expert-parallel host logic on CPU with the gloo backend, world_size 2.
+
+The kernels need a GPU, so here the eve_amd exchange (`_AllToAll`, the [ep, E_local, C, M] layout
+of MOELayer.forward) is exercised with the CPU oracle standing in for gate / dispatch / experts /
+combine.  Expected values: the reference's own per-rank outputs (tests/golden/ep_small.npz)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.manual_seed(0)
+        torch.set_num_threads(2)
+        from eve_amd.sharded_moe import _AllToAll
+        from oracle import moe_oracle as orc
+        z = np.load(os.path.join(REPO, "tests", "golden", "ep_small.npz"))
+        lz = np.load(os.path.join(REPO, "tests", "golden", "layer_small.npz"))
+        p = {k[2:]: torch.from_numpy(lz[k]) for k in lz.files if k.startswith("p/")}
+        M, I, E, n_vis = int(lz["M"]), int(lz["I"]), int(lz["E"]), int(lz["n_vis"])
+        e_local = E // world
+        lo = rank * e_local
+        # this rank owns experts [lo, lo + e_local); gate / embeddings are replicated
+        w1 = p["w1"][lo:lo + e_local].clone().requires_grad_(True)
+        b1 = p["b1"][lo:lo + e_local].clone().requires_grad_(True)
+        w2 = p["w2"][lo:lo + e_local].clone().requires_grad_(True)
+        b2 = p["b2"][lo:lo + e_local].clone().requires_grad_(True)
+        h = torch.from_numpy(z[f"r{rank}/h"]).requires_grad_(True)
+        noise, dout = torch.from_numpy(z[f"r{rank}/noise"]), torch.from_numpy(z[f"r{rank}/dout"])
+        x = orc.modality_input(h, p, "vl", n_vis)
+        S = x.shape[0]
+        logits = x @ p["wg"].t()
+        r = orc.index_top2gating(logits, noise, 1.0, 4)
+        C = r.C
+        # dispatch into [E, C, M] (zeros in empty slots), as eve_dispatch_fwd does
+        xd = torch.zeros(E * C, M)
+        for slot in (r.slot1, r.slot2):
+            sel = torch.nonzero(slot >= 0).flatten()
+            xd = xd.index_put((slot[sel],), x[sel])
+        # ---- the code under test: exchange + layout (eve_amd/sharded_moe.py MOELayer.forward)
+        recv = _AllToAll.apply(dist.group.WORLD, xd.view(world, -1)).view(world, e_local, C, M)
+        ys = []
+        for src in range(world):
+            ys.append(torch.stack([orc.expert_ffn(recv[src, j], w1[j], b1[j], w2[j], b2[j]) for j in range(e_local)]))
+        y = torch.stack(ys)  # [ep, E_local, C, M]
+        back = _AllToAll.apply(dist.group.WORLD, y.reshape(world, -1)).view(E * C, M)
+        out = torch.zeros(S, M)
+        for slot, w in ((r.slot1, r.w1), (r.slot2, r.w2)):
+            sel = torch.nonzero(slot >= 0).flatten()
+            out = out.index_add(0, sel, w[sel, None] * back[slot[sel]])
+        out = out.view(h.shape)
+        ((out * dout).sum() + float(z["aux_w"]) * r.l_aux).backward()
+        np.testing.assert_allclose(out.detach().numpy(), z[f"r{rank}/out"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(h.grad.numpy(), z[f"r{rank}/dh"], rtol=1e-4, atol=2e-6)
+        assert np.array_equal(r.exp_counts.numpy(), z[f"r{rank}/exp_counts"])
+        # expert gradients on the owner = SUM over ranks of what each rank's tokens contribute; compare
+        # with the sum of the first `world` ranks' independent reference gradients (recomputed by the
+        # oracle because the golden 'sum/' entries cover all 8 ranks)
+        tot = None
+        for rr in range(world):
+            pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            hh = torch.from_numpy(z[f"r{rr}/h"])
+            o, la, _, _ = orc.index_moe_forward(hh, pr, torch.from_numpy(z[f"r{rr}/noise"]), mode="vl", n_vis=n_vis)
+            ((o * torch.from_numpy(z[f"r{rr}/dout"])).sum() + float(z["aux_w"]) * la).backward()
+            g = [pr[k].grad[lo:lo + e_local] for k in ("w1", "b1", "w2", "b2")]
+            tot = g if tot is None else [a + b for a, b in zip(tot, g)]
+        for got, ref in zip((w1.grad, b1.grad, w2.grad, b2.grad), tot):
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=5e-6)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def test_expert_parallel_exchange_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(m == "ok" for _, m in res), res
+
+
+def test_moelayer_ep_group_resolution_errors():
+    import eve_amd
+    moe = eve_amd.MoE(32, eve_amd.MultiwayTransformerMLP("quick_gelu", 32, 64), num_experts=8, ep_size=2, k=2)
+    assert moe.num_local_experts == 4 and len(moe.moe.experts.experts) == 4
+    with pytest.raises(RuntimeError, match="torch.distributed"):
+        moe.moe._resolve_ep_group()
