@@ -7,7 +7,7 @@
 namespace eve {
 
 constexpr float kEps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps, sharded_moe.py:221
-constexpr int kGateBlock = 256;                  // tokens per block in the select / assign passes
+constexpr int kGateBlock = 64;                   // tokens per block (one wave) in the select / assign passes
 
 // =============================================================== logits = x @ wg^T
 // One wave handles TOK tokens at a time; lane l owns 4-element granules l, l+64, ... of
@@ -85,22 +85,23 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const T* __restrict__ 
 __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
     const float* __restrict__ logits, const float* __restrict__ noise, int S, int E, float* __restrict__ gates,
     int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank, float* __restrict__ gsum,
-    int32_t* __restrict__ slot_token, int num_slots) {
+    int32_t* __restrict__ slot_token, int num_slots, int use_tile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nw = kGateBlock / 64;
-  int32_t* wcnt = reinterpret_cast<int32_t*>(smem);                  // [nw][2][E]
-  float* gcol = reinterpret_cast<float*>(wcnt + nw * 2 * E);         // [nw][E] wave partial sums
+  static_assert(kGateBlock == 64, "one wave per block");
+  float* tile = reinterpret_cast<float*>(smem);  // [64][E+1] gates of the block's tokens (use_tile)
 
   // clear the inverse map (consumed by pass 3, which runs after this kernel completes)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_slots; i += gridDim.x * blockDim.x) slot_token[i] = -1;
 
   const int s = blockIdx.x * kGateBlock + threadIdx.x;
   const bool live = s < S;
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int lane = lane_id();
   const float* row = logits + (size_t)(live ? s : 0) * E;
   const float* nrow = noise + (size_t)(live ? s : 0) * E;
+  float* grow = gates + (size_t)(live ? s : 0) * E;
 
-  // softmax exactly as exp(x - max) / sum; first choice = argmax of the GATES (ties -> lowest e)
+  // softmax exactly as exp(x - max) / sum; first choice = argmax of the GATES (ties -> lowest e);
+  // second choice = argmax of logits + noise with the first choice masked out
   float mx = -INFINITY;
   for (int e = 0; e < E; ++e) mx = fmaxf(mx, row[e]);
   float sum = 0.f;
@@ -109,10 +110,10 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
   float best = -INFINITY;
   for (int e = 0; e < E; ++e) {
     const float g = expf(row[e] - mx) / sum;
-    if (live) gates[(size_t)s * E + e] = g;
+    if (live) grow[e] = g;
+    if (use_tile) tile[threadIdx.x * (E + 1) + e] = live ? g : 0.f;
     if (g > best) { best = g; i1 = e; }
   }
-  // second choice = argmax of logits + noise with the first choice masked out
   int i2 = -1;
   float best2 = -INFINITY;
   for (int e = 0; e < E; ++e) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
   if (i2 < 0) i2 = 0;  // E == 1: masked_fill leaves all -inf, argmax -> 0
   if (!live) { i1 = -1; i2 = -1; }
 
-  // ranks inside the wave, counts per wave
+  // rank of each token among the block's earlier tokens with the same choice; block histograms
   int r1 = 0, r2 = 0;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int e = 0; e < E; ++e) {
@@ -132,34 +133,28 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
     if (i1 == e) r1 = __popcll(m1 & lt);
     if (i2 == e) r2 = __popcll(m2 & lt);
     if (lane == 0) {
-      wcnt[(wave * 2 + 0) * E + e] = __popcll(m1);
-      wcnt[(wave * 2 + 1) * E + e] = __popcll(m2);
+      hist[(size_t)blockIdx.x * 2 * E + e] = __popcll(m1);
+      hist[(size_t)blockIdx.x * 2 * E + E + e] = __popcll(m2);
     }
-    // column sum of gates over the wave's tokens (fixed order -> deterministic)
-    float g = live ? gates[(size_t)s * E + e] : 0.f;
-    g = wave_sum(g);
-    if (lane == 0) gcol[wave * E + e] = g;
+    if (!use_tile) {  // column sum of gates over the block's tokens, butterfly (fixed order)
+      float g = live ? grow[e] : 0.f;
+      g = wave_sum(g);
+      if (lane == 0) gsum[(size_t)blockIdx.x * E + e] = g;
+    }
   }
-  __syncthreads();
   if (live) {
-    for (int w = 0; w < wave; ++w) {
-      r1 += wcnt[(w * 2 + 0) * E + i1];
-      r2 += wcnt[(w * 2 + 1) * E + i2];
-    }
     idx[2 * s] = i1;
     idx[2 * s + 1] = i2;
     rank[2 * s] = r1;
     rank[2 * s + 1] = r2;
   }
-  for (int t = threadIdx.x; t < 2 * E; t += blockDim.x) {
-    int c = 0;
-    for (int w = 0; w < nw; ++w) c += wcnt[w * 2 * E + t];
-    hist[(size_t)blockIdx.x * 2 * E + t] = c;
-  }
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    float g = 0.f;
-    for (int w = 0; w < nw; ++w) g += gcol[w * E + e];
-    gsum[(size_t)blockIdx.x * E + e] = g;
+  if (use_tile) {  // column sums from the LDS tile: lane e walks the 64 rows in order
+    __syncthreads();
+    for (int e = lane; e < E; e += 64) {
+      float g = 0.f;
+      for (int r = 0; r < kGateBlock; ++r) g += tile[r * (E + 1) + e];
+      gsum[(size_t)blockIdx.x * E + e] = g;
+    }
   }
 }
 
@@ -345,12 +340,174 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   out[i] = acc;
 }
 
+// ======================================================== fp32-MFMA versions (E <= 32)
+// v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain at the VALU rate, but one instruction does a
+// 32x32x2 block, which removes the per-element operand traffic of the VALU kernels above.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// modality-added, dtype-rounded activation element
+template <typename T>
+__device__ __forceinline__ float x_elem(const T* __restrict__ hp, const T* __restrict__ emb, int col) {
+  float v = to_f32<T>(hp[col]);
+  if (emb) v = to_f32<T>(from_f32<T>(v + to_f32<T>(emb[col])));
+  return v;
+}
+
+// logits tile: D[32 tokens x 32 experts] += A[32 tokens x 2 k] * B[2 k x 32 experts].  One wave per 32
+// tokens.  Lane (i = lane & 31, hh = lane >> 5) supplies, for each 16-wide k block, the 8 contiguous
+// elements k0 + 8*hh .. +8 of token i (A) and of expert i (B): MFMA step j multiplies k0+j and k0+8+j.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
+                                                               const T* __restrict__ temb,
+                                                               const float* __restrict__ wg,
+                                                               float* __restrict__ logits, int S, int T_, int n_vis,
+                                                               int mode, int M, int E) {
+  const int lane = lane_id();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int s0 = wave * 32;
+  if (s0 >= S) return;
+  const int i = lane & 31, hh = lane >> 5;
+  const int s = min(s0 + i, S - 1);
+  const T* hp = h + (size_t)s * M;
+  const T* emb = nullptr;
+  if (mode != EVE_MODE_NONE) emb = token_modality(s, T_, n_vis, mode) ? temb : vemb;
+  const float* wp = wg + (size_t)min(i, E - 1) * M;
+  const float wmask = i < E ? 1.f : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int KU = 4;  // 16-wide k blocks whose loads are issued together (latency hiding)
+  for (int k0 = 0; k0 < M; k0 += 16 * KU) {
+    float a[KU][8], b[KU][8];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k = min(k0 + 16 * u, M - 16) + 8 * hh;  // clamp: blocks past M are masked below
+      const Vec16<T> hv0 = load16<T>(hp + k);
+      if constexpr (Vec16<T>::N == 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[u][j] = hv0.get(j);
+        if (emb) {
+          const Vec16<T> ev = load16<T>(emb + k);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[u][j] = to_f32<T>(from_f32<T>(a[u][j] + ev.get(j)));
+        }
+      } else {
+        const Vec16<T> hv1 = load16<T>(hp + k + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[u][j] = hv0.get(j); a[u][4 + j] = hv1.get(j); }
+        if (emb) {
+          const Vec16<T> e0 = load16<T>(emb + k), e1 = load16<T>(emb + k + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[u][j] += e0.get(j); a[u][4 + j] += e1.get(j); }
+        }
+      }
+      const float m = (k0 + 16 * u < M) ? wmask : 0.f;
+      const float4 w0 = *reinterpret_cast<const float4*>(wp + k), w1 = *reinterpret_cast<const float4*>(wp + k + 4);
+      b[u][0] = w0.x * m; b[u][1] = w0.y * m; b[u][2] = w0.z * m; b[u][3] = w0.w * m;
+      b[u][4] = w1.x * m; b[u][5] = w1.y * m; b[u][6] = w1.z * m; b[u][7] = w1.w * m;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc, 0, 0, 0);
+  }
+  // D: column (expert) = lane & 31, row (token) = (r & 3) + 8 * (r >> 2) + 4 * hh
+  if (i < E) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (s0 + row < S) logits[(size_t)(s0 + row) * E + i] = acc[r];
+    }
+  }
+}
+
+// dwg partials: D[32 experts x 32 "virtual" cols] += A[32 experts x 2 tokens] * B[2 tokens x 32 cols].
+// A block owns a chunk of TS tokens; wave w owns columns [256 w, 256 w + 256).  Lane i loads the 8
+// contiguous elements at column 256 w + 8 i of a token with one (bf16) or two (fp32) 16-byte loads
+// and feeds element t to MFMA t, i.e. accumulator t's column j stands for real column 256 w + 8 j + t.
+template <typename T>
+__global__ __launch_bounds__(256) void gate_wgrad_mfma_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
+                                                              const T* __restrict__ temb,
+                                                              const float* __restrict__ dlogits,
+                                                              float* __restrict__ part, int S, int T_, int n_vis,
+                                                              int mode, int M, int E, int TS) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int i = lane & 31, hh = lane >> 5;
+  const int col0 = wave * 256 + i * 8;
+  if (wave * 256 >= M) return;  // whole wave has no columns
+  const bool col_ok = col0 < M;   // M % 8 == 0
+  const int s_begin = blockIdx.x * TS, s_end = min(S, s_begin + TS);
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  constexpr int PU = 4;  // token pairs whose loads are issued together
+  for (int s2 = s_begin; s2 < s_end; s2 += 2 * PU) {
+    float a[PU], b[PU][8];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int s = s2 + 2 * u + hh;
+      const bool live = s < s_end;
+      const int sc = live ? s : s_begin;
+      a[u] = (live && i < E) ? dlogits[(size_t)sc * E + i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[u][j] = 0.f;
+      if (live && col_ok) {
+        const T* hp = h + (size_t)sc * M + col0;
+        const T* emb = nullptr;
+        if (mode != EVE_MODE_NONE) emb = (token_modality(sc, T_, n_vis, mode) ? temb : vemb) + col0;
+        if constexpr (Vec16<T>::N == 8) {
+          const Vec16<T> hv = load16<T>(hp);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) b[u][j] = hv.get(j);
+          if (emb) {
+            const Vec16<T> ev = load16<T>(emb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[u][j] = to_f32<T>(from_f32<T>(b[u][j] + ev.get(j)));
+          }
+        } else {
+          const Vec16<T> h0 = load16<T>(hp), h1 = load16<T>(hp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { b[u][j] = h0.get(j); b[u][4 + j] = h1.get(j); }
+          if (emb) {
+            const Vec16<T> e0 = load16<T>(emb), e1 = load16<T>(emb + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { b[u][j] += e0.get(j); b[u][4 + j] += e1.get(j); }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+  }
+  if (!col_ok) return;
+  float* out = part + (size_t)blockIdx.x * E * M;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;  // expert
+    if (row >= E) continue;
+    float* o = out + (size_t)row * M + col0;
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+  }
+}
+
 // =================================================================== host launchers
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 template <typename T>
 static int launch_logits(const void* h, const void* ve, const void* te, const float* wg, float* logits, int S, int T_,
                          int n_vis, int mode, int M, int E, hipStream_t st) {
+  if (E <= 32 && M % 16 == 0) {
+    const int waves = ceil_div(S, 32);
+    hipLaunchKernelGGL((gate_logits_mfma_kernel<T>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, (const T*)h,
+                       (const T*)ve, (const T*)te, wg, logits, S, T_, n_vis, mode, M, E);
+    EVE_CHECK_LAUNCH("gate_logits_mfma_kernel");
+    return EVE_OK;
+  }
   const int ngran = M / 4;
   const int ng = ceil_div(ngran, 64);
   constexpr int TOK = 4;
@@ -441,10 +598,10 @@ extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int S,
   float* gsum = reinterpret_cast<float*>(ws + w.gsum);
   int32_t* tot = reinterpret_cast<int32_t*>(ws + w.tot);
   hipStream_t st = S_(stream);
-  const int nw = kGateBlock / 64;
-  const size_t lds1 = (size_t)nw * 2 * E * 4 + (size_t)nw * E * 4;
+  const int use_tile = E <= 128 ? 1 : 0;
+  const size_t lds1 = use_tile ? (size_t)kGateBlock * (E + 1) * 4 : 0;
   hipLaunchKernelGGL(gate_select_kernel, dim3(w.nblk), dim3(kGateBlock), lds1, st, logits, noise, S, E, gates, idx,
-                     hist, rank, gsum, slot_token, E * C);
+                     hist, rank, gsum, slot_token, E * C, use_tile);
   EVE_CHECK_LAUNCH("gate_select_kernel");
   const size_t lds2 = (size_t)3 * E * 4;
   hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(1024), lds2, st, hist, boff, gsum, tot, exp_counts, rows, l_aux, S,
@@ -467,11 +624,13 @@ extern "C" int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const i
   return EVE_OK;
 }
 
-static const int kWgradTS = 64;
+static const int kWgradTS = 64;       // VALU kernel
+static const int kWgradMfmaTS = 128;  // fp32-MFMA kernel
+static inline bool wgrad_use_mfma(int M, int E) { return E <= 32 && M % 8 == 0 && M <= 1024; }
 
 extern "C" size_t eve_gate_wgrad_workspace_bytes(int S, int M, int E) {
   if (S <= 0) return 0;
-  return (size_t)ceil_div(S, kWgradTS) * E * M * sizeof(float);
+  return (size_t)ceil_div(S, wgrad_use_mfma(M, E) ? kWgradMfmaTS : kWgradTS) * E * M * sizeof(float);
 }
 
 extern "C" int eve_gate_wgrad(const void* h, const void* vision_embed, const void* text_embed, const float* dlogits,
@@ -483,9 +642,26 @@ extern "C" int eve_gate_wgrad(const void* h, const void* vision_embed, const voi
   if (mode != EVE_MODE_NONE) EVE_REQUIRE(vision_embed && text_embed && T > 0, EVE_ERR_ARG, "eve_gate_wgrad: embeddings required");
   const size_t need = eve_gate_wgrad_workspace_bytes(S, M, E);
   EVE_REQUIRE(workspace_bytes >= need, EVE_ERR_WORKSPACE, "eve_gate_wgrad: workspace %zu < %zu", workspace_bytes, need);
-  const int nb = ceil_div(S, kWgradTS);
   float* part = static_cast<float*>(workspace);
   hipStream_t st = S_(stream);
+  if (wgrad_use_mfma(M, E)) {
+    const int nbm = ceil_div(S, kWgradMfmaTS);
+    EVE_REQUIRE(dtype == EVE_F32 || dtype == EVE_BF16, EVE_ERR_ARG, "eve_gate_wgrad: bad dtype %d", dtype);
+    if (dtype == EVE_F32)
+      hipLaunchKernelGGL((gate_wgrad_mfma_kernel<float>), dim3(nbm), dim3(256), 0, st, (const float*)h,
+                         (const float*)vision_embed, (const float*)text_embed, dlogits, part, S, T, n_vis, mode, M, E,
+                         kWgradMfmaTS);
+    else
+      hipLaunchKernelGGL((gate_wgrad_mfma_kernel<bf16_t>), dim3(nbm), dim3(256), 0, st, (const bf16_t*)h,
+                         (const bf16_t*)vision_embed, (const bf16_t*)text_embed, dlogits, part, S, T, n_vis, mode, M,
+                         E, kWgradMfmaTS);
+    EVE_CHECK_LAUNCH("gate_wgrad_mfma_kernel");
+    const int nn = E * M;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(nn, 256)), dim3(256), 0, st, part, dwg, nn, nbm);
+    EVE_CHECK_LAUNCH("sum_partials_kernel");
+    return EVE_OK;
+  }
+  const int nb = ceil_div(S, kWgradTS);
   const size_t lds = (size_t)kWgradTS * 32 * 4;
   if (dtype == EVE_F32)
     hipLaunchKernelGGL((gate_wgrad_partial_kernel<float, 32>), dim3(nb), dim3(256), lds, st, (const float*)h,

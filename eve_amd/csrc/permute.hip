@@ -5,8 +5,6 @@
 
 namespace eve {
 
-constexpr int kRowsPerWave = 2;  // rows in flight per wave iteration
-
 // ----------------------------------------------------------------------------- dispatch fwd
 // xd[slot] = round(h[tok] + emb(tok)) or 0.  One wave per slot row.
 template <typename T>
@@ -42,52 +40,73 @@ __global__ __launch_bounds__(256) void dispatch_fwd_kernel(const T* __restrict__
 }
 
 // ----------------------------------------------------------------------------- dispatch bwd
-// dh[s] = dxd[slot1] + dxd[slot2] + dlogits[s,:] @ wg.  One wave per token.
+// dh[s] = dxd[slot1] + dxd[slot2] + dlogits[s,:] @ wg.  A block owns TOKB consecutive tokens and
+// each thread one 16-byte column chunk, so every wg chunk fetched (L2-resident) is used for TOKB
+// tokens; the block's dlogits rows sit in LDS and are read as broadcasts.
+constexpr int kDbTok = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void dispatch_bwd_kernel(const T* __restrict__ dxd, const int32_t* __restrict__ slot,
+__global__ __launch_bounds__(128) void dispatch_bwd_kernel(const T* __restrict__ dxd, const int32_t* __restrict__ slot,
                                                            const float* __restrict__ dlogits,
                                                            const float* __restrict__ wg, T* __restrict__ dh, int S,
                                                            int M, int E) {
   constexpr int N = Vec16<T>::N;
-  const int lane = lane_id();
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dl = reinterpret_cast<float*>(smem);  // [E][kDbTok]
+  const int s0 = blockIdx.x * kDbTok;
+  const int ntok = min(kDbTok, S - s0);
+  if (dlogits) {
+    for (int i = threadIdx.x; i < E * kDbTok; i += blockDim.x) {
+      const int e = i / kDbTok, t = i % kDbTok;
+      dl[i] = t < ntok ? dlogits[(size_t)(s0 + t) * E + e] : 0.f;
+    }
+    __syncthreads();
+  }
   const int chunks = M / N;
-  for (int s = wave; s < S; s += nwaves) {
-    const int s1 = slot[2 * s], s2 = slot[2 * s + 1];
-    const float* dl = dlogits ? dlogits + (size_t)s * E : nullptr;
-    for (int c = lane; c < chunks; c += 64) {
-      float acc[N];
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    float acc[kDbTok][N];
 #pragma unroll
-      for (int j = 0; j < N; ++j) acc[j] = 0.f;
-      if (s1 >= 0) {
-        const Vec16<T> v = load16<T>(dxd + (size_t)s1 * M + c * N);
+    for (int t = 0; t < kDbTok; ++t) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += v.get(j);
-      }
-      if (s2 >= 0) {
-        const Vec16<T> v = load16<T>(dxd + (size_t)s2 * M + c * N);
+      for (int j = 0; j < N; ++j) acc[t][j] = 0.f;
+      if (t < ntok) {
+        const int s1 = slot[2 * (s0 + t)], s2 = slot[2 * (s0 + t) + 1];
+        if (s1 >= 0) {
+          const Vec16<T> v = load16<T>(dxd + (size_t)s1 * M + c * N);
 #pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += v.get(j);
-      }
-      if (dl) {
-        for (int e = 0; e < E; ++e) {
-          const float d = dl[e];
-          const float* w = wg + (size_t)e * M + c * N;
+          for (int j = 0; j < N; ++j) acc[t][j] += v.get(j);
+        }
+        if (s2 >= 0) {
+          const Vec16<T> v = load16<T>(dxd + (size_t)s2 * M + c * N);
 #pragma unroll
-          for (int j = 0; j < N; j += 4) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + j);
-            acc[j] = fmaf(d, wv.x, acc[j]);
-            acc[j + 1] = fmaf(d, wv.y, acc[j + 1]);
-            acc[j + 2] = fmaf(d, wv.z, acc[j + 2]);
-            acc[j + 3] = fmaf(d, wv.w, acc[j + 3]);
-          }
+          for (int j = 0; j < N; ++j) acc[t][j] += v.get(j);
         }
       }
+    }
+    if (dlogits) {
+      for (int e = 0; e < E; ++e) {
+        float w[N];
+        const float* wp = wg + (size_t)e * M + c * N;
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+          const float4 wv = *reinterpret_cast<const float4*>(wp + j);
+          w[j] = wv.x; w[j + 1] = wv.y; w[j + 2] = wv.z; w[j + 3] = wv.w;
+        }
+        const float4 d0 = *reinterpret_cast<const float4*>(dl + e * kDbTok);
+        const float4 d1 = *reinterpret_cast<const float4*>(dl + e * kDbTok + 4);
+        const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int t = 0; t < kDbTok; ++t)
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc[t][j] = fmaf(d[t], w[j], acc[t][j]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kDbTok; ++t) {
+      if (t >= ntok) continue;
       Vec16<T> o;
 #pragma unroll
-      for (int j = 0; j < N; ++j) o.set(j, acc[j]);
-      store16<T>(dh + (size_t)s * M + c * N, o);
+      for (int j = 0; j < N; ++j) o.set(j, acc[t][j]);
+      store16<T>(dh + (size_t)(s0 + t) * M + c * N, o);
     }
   }
 }
@@ -193,34 +212,53 @@ __global__ __launch_bounds__(256) void combine_bwd_dw_kernel(const T* __restrict
 }
 
 // ------------------------------------------------------------------ modality embed gradient
-// Column sums of dh by modality.  Stage 1: block (chunk of TS tokens) x (column tile of 256
-// columns) -> part[chunk][2][M]; stage 2: fixed-order sum over chunks.
+// Column sums of dh by modality.  Stage 1: block = chunk of TS tokens, thread = one 16-byte column
+// chunk -> part[chunk][2][M]; stage 2: fixed-order sum over chunks (8 row groups x 32 columns per
+// block, LDS tree).  Deterministic.
 template <typename T>
-__global__ __launch_bounds__(256) void embed_grad_partial_kernel(const T* __restrict__ dh, float* __restrict__ part,
+__global__ __launch_bounds__(128) void embed_grad_partial_kernel(const T* __restrict__ dh, float* __restrict__ part,
                                                                  int S, int T_, int n_vis, int mode, int M, int TS) {
-  const int col = blockIdx.y * blockDim.x + threadIdx.x;
-  if (col >= M) return;
+  constexpr int N = Vec16<T>::N;
+  const int chunks = M / N;
   const int s0 = blockIdx.x * TS, s1 = min(S, s0 + TS);
-  float av = 0.f, at = 0.f;
-  for (int s = s0; s < s1; ++s) {
-    const float v = to_f32<T>(dh[(size_t)s * M + col]);
-    if (token_modality(s, T_, n_vis, mode)) at += v; else av += v;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    float av[N], at[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) av[j] = at[j] = 0.f;
+    for (int s = s0; s < s1; ++s) {
+      const Vec16<T> v = load16<T>(dh + (size_t)s * M + c * N);
+      if (token_modality(s, T_, n_vis, mode)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) at[j] += v.get(j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) av[j] += v.get(j);
+      }
+    }
+    float* pv = part + ((size_t)blockIdx.x * 2 + 0) * M + c * N;
+    float* pt = part + ((size_t)blockIdx.x * 2 + 1) * M + c * N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { pv[j] = av[j]; pt[j] = at[j]; }
   }
-  part[((size_t)blockIdx.x * 2 + 0) * M + col] = av;
-  part[((size_t)blockIdx.x * 2 + 1) * M + col] = at;
 }
 
 __global__ __launch_bounds__(256) void embed_grad_final_kernel(const float* __restrict__ part, float* __restrict__ dv,
                                                                float* __restrict__ dt, int M, int nchunks) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= M) return;
-  float av = 0.f, at = 0.f;
-  for (int b = 0; b < nchunks; ++b) {
-    av += part[((size_t)b * 2 + 0) * M + col];
-    at += part[((size_t)b * 2 + 1) * M + col];
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;   // over 2*M columns: [vision M | text M] per chunk row
+  float acc = 0.f;
+  if (col < 2 * M)
+    for (int b = ty; b < nchunks; b += 8) acc += part[(size_t)b * 2 * M + col];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && col < 2 * M) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][tx];
+    if (col < M) { if (dv) dv[col] = s; }
+    else if (dt) dt[col - M] = s;
   }
-  if (dv) dv[col] = av;
-  if (dt) dt[col] = at;
 }
 
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -271,12 +309,14 @@ extern "C" int eve_dispatch_bwd(const void* dxd, const int32_t* slot, const floa
   EVE_REQUIRE(S > 0 && E > 0, EVE_ERR_ARG, "eve_dispatch_bwd: bad shape");
   if (int rc = check_rows("eve_dispatch_bwd", M, dtype)) return rc;
   hipStream_t st = S_(stream);
+  const dim3 grid(ceil_div(S, kDbTok));
+  const size_t lds = (size_t)E * kDbTok * sizeof(float);
   if (dtype == EVE_F32)
-    hipLaunchKernelGGL((dispatch_bwd_kernel<float>), dim3(row_grid(S)), dim3(256), 0, st, (const float*)dxd, slot,
-                       dlogits, wg, (float*)dh, S, M, E);
+    hipLaunchKernelGGL((dispatch_bwd_kernel<float>), grid, dim3(128), lds, st, (const float*)dxd, slot, dlogits, wg,
+                       (float*)dh, S, M, E);
   else
-    hipLaunchKernelGGL((dispatch_bwd_kernel<bf16_t>), dim3(row_grid(S)), dim3(256), 0, st, (const bf16_t*)dxd, slot,
-                       dlogits, wg, (bf16_t*)dh, S, M, E);
+    hipLaunchKernelGGL((dispatch_bwd_kernel<bf16_t>), grid, dim3(128), lds, st, (const bf16_t*)dxd, slot, dlogits, wg,
+                       (bf16_t*)dh, S, M, E);
   EVE_CHECK_LAUNCH("dispatch_bwd_kernel");
   return EVE_OK;
 }
@@ -319,7 +359,7 @@ extern "C" int eve_combine_bwd(const void* dout, const void* y, const int32_t* s
   return EVE_OK;
 }
 
-static const int kEmbedTS = 128;
+static const int kEmbedTS = 32;
 
 extern "C" size_t eve_embed_grad_workspace_bytes(int S, int M) {
   if (S <= 0 || M <= 0) return 0;
@@ -337,15 +377,14 @@ extern "C" int eve_embed_grad(const void* dh, float* dvision, float* dtext, int 
   const int nchunks = ceil_div(S, kEmbedTS);
   float* part = static_cast<float*>(workspace);
   hipStream_t st = S_(stream);
-  dim3 grid(nchunks, ceil_div(M, 256));
   if (dtype == EVE_F32)
-    hipLaunchKernelGGL((embed_grad_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)dh, part, S, T, n_vis,
-                       mode, M, kEmbedTS);
+    hipLaunchKernelGGL((embed_grad_partial_kernel<float>), dim3(nchunks), dim3(128), 0, st, (const float*)dh, part, S,
+                       T, n_vis, mode, M, kEmbedTS);
   else
-    hipLaunchKernelGGL((embed_grad_partial_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dh, part, S, T,
-                       n_vis, mode, M, kEmbedTS);
+    hipLaunchKernelGGL((embed_grad_partial_kernel<bf16_t>), dim3(nchunks), dim3(128), 0, st, (const bf16_t*)dh, part,
+                       S, T, n_vis, mode, M, kEmbedTS);
   EVE_CHECK_LAUNCH("embed_grad_partial_kernel");
-  hipLaunchKernelGGL(embed_grad_final_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, part, dvision, dtext, M,
+  hipLaunchKernelGGL(embed_grad_final_kernel, dim3(ceil_div(2 * M, 32)), dim3(256), 0, st, part, dvision, dtext, M,
                      nchunks);
   EVE_CHECK_LAUNCH("embed_grad_final_kernel");
   return EVE_OK;
