@@ -77,10 +77,10 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const T* __restrict__ 
 // among earlier tokens OF ITS BLOCK with the same choice (wave ballots + LDS), per-block
 // histograms and per-block column sums of the gates.  Also clears slot_token.
 // Workspace layout (ints unless noted), nblk = ceil(S / kGateBlock):
-//   hist   [nblk][2][E]   block histograms of first / second choices
-//   boff   [nblk][2][E]   exclusive prefix of hist over blocks (pass 2)
+//   hist   [2][E][nblk]   block histograms of first / second choices (block index fastest)
+//   boff   [2][E][nblk]   exclusive prefix of hist over blocks (pass 2)
 //   rank   [S][2]         in-block rank
-//   gsum   [nblk][E]      float, per-block column sums of gates
+//   gsum   [E][nblk]      float, per-block column sums of gates
 //   tot    [2][E]         totals
 __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
     const float* __restrict__ logits, const float* __restrict__ noise, int S, int E, float* __restrict__ gates,
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
     if (i1 == e) r1 = __popcll(m1 & lt);
     if (i2 == e) r2 = __popcll(m2 & lt);
     if (lane == 0) {
-      hist[(size_t)blockIdx.x * 2 * E + e] = __popcll(m1);
-      hist[(size_t)blockIdx.x * 2 * E + E + e] = __popcll(m2);
+      hist[(size_t)e * gridDim.x + blockIdx.x] = __popcll(m1);
+      hist[(size_t)(E + e) * gridDim.x + blockIdx.x] = __popcll(m2);
     }
     if (!use_tile) {  // column sum of gates over the block's tokens, butterfly (fixed order)
       float g = live ? grow[e] : 0.f;
       g = wave_sum(g);
-      if (lane == 0) gsum[(size_t)blockIdx.x * E + e] = g;
+      if (lane == 0) gsum[(size_t)e * gridDim.x + blockIdx.x] = g;
     }
   }
   if (live) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
     for (int e = lane; e < E; e += 64) {
       float g = 0.f;
       for (int r = 0; r < kGateBlock; ++r) g += tile[r * (E + 1) + e];
-      gsum[(size_t)blockIdx.x * E + e] = g;
+      gsum[(size_t)e * gridDim.x + blockIdx.x] = g;
     }
   }
 }
@@ -168,20 +168,37 @@ __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restri
   int32_t* stot = reinterpret_cast<int32_t*>(smem);   // [2E]
   float* sme = reinterpret_cast<float*>(stot + 2 * E);  // [E]
   const int lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // Each wave scans one (choice, expert) row of hist at a time, 256 blocks per step: lane l owns
+  // blocks 4l .. 4l+3 (one 16-byte load), the 64 lane totals are scanned across the wave, and the
+  // lane writes its four exclusive prefixes with one 16-byte store.  nblk is padded to a multiple of 4
+  // in the workspace layout, so the vector accesses stay inside the row.
+  const int nb4 = (nblk + 3) & ~3;
   for (int pair = wave; pair < 2 * E; pair += nw) {
+    const int32_t* hrow = hist + (size_t)pair * nblk;
+    int32_t* brow = boff + (size_t)pair * nblk;
     int carry = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 64) {
-      const int b = b0 + lane;
-      const int v = b < nblk ? hist[(size_t)b * 2 * E + pair] : 0;
-      const int inc = wave_incl_scan(v);
-      if (b < nblk) boff[(size_t)b * 2 * E + pair] = carry + inc - v;
+    for (int c0 = 0; c0 < nblk; c0 += 256) {
+      const int b = c0 + 4 * lane;
+      int v[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (b + j < nblk) v[j] = hrow[b + j];
+      const int run = v[0] + v[1] + v[2] + v[3];
+      const int inc = wave_incl_scan(run);
+      int pre = carry + inc - run;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (b + j < nblk) brow[b + j] = pre;
+        pre += v[j];
+      }
       carry += __shfl(inc, 63, 64);
     }
     if (lane == 0) stot[pair] = carry;
   }
+  (void)nb4;
   for (int e = wave; e < E; e += nw) {  // fixed lane-strided order, then butterfly: deterministic
     float g = 0.f;
-    for (int b = lane; b < nblk; b += 64) g += gsum[(size_t)b * E + e];
+    for (int b = lane; b < nblk; b += 64) g += gsum[(size_t)e * nblk + b];
     g = wave_sum(g);
     if (lane == 0) sme[e] = g;
   }
@@ -214,9 +231,9 @@ __global__ __launch_bounds__(kGateBlock) void gate_assign_kernel(
   const int s = blockIdx.x * kGateBlock + threadIdx.x;
   if (s >= S) return;
   const int i1 = idx[2 * s], i2 = idx[2 * s + 1];
-  const int32_t* bo = boff + (size_t)blockIdx.x * 2 * E;
-  const int l1 = bo[i1] + rank[2 * s];
-  const int l2 = bo[E + i2] + rank[2 * s + 1] + tot[i2];  // 2nd choices queue behind ALL 1st choices
+  const int nblk = gridDim.x;
+  const int l1 = boff[(size_t)i1 * nblk + blockIdx.x] + rank[2 * s];
+  const int l2 = boff[(size_t)(E + i2) * nblk + blockIdx.x] + rank[2 * s + 1] + tot[i2];  // behind ALL 1st choices
   const bool k1 = l1 < C, k2 = l2 < C;
   const float g1 = k1 ? gates[(size_t)s * E + i1] : 0.f;
   const float g2 = k2 ? gates[(size_t)s * E + i2] : 0.f;
@@ -353,21 +370,25 @@ __device__ __forceinline__ float x_elem(const T* __restrict__ hp, const T* __res
   return v;
 }
 
-// logits tile: D[32 tokens x 32 experts] += A[32 tokens x 2 k] * B[2 k x 32 experts].  One wave per 32
-// tokens.  Lane (i = lane & 31, hh = lane >> 5) supplies, for each 16-wide k block, the 8 contiguous
-// elements k0 + 8*hh .. +8 of token i (A) and of expert i (B): MFMA step j multiplies k0+j and k0+8+j.
+// logits tile: D[32 tokens x 32 experts] += A[32 tokens x 2 k] * B[2 k x 32 experts].  One block per 32
+// tokens; its 4 waves split the K axis and their partial tiles are summed through LDS in wave order
+// (deterministic).  Lane (i = lane & 31, hh = lane >> 5) supplies, for each 16-wide k block, the 8
+// contiguous elements k0 + 8*hh .. +8 of token i (A) and of expert i (B): MFMA step j multiplies
+// k0+j and k0+8+j.
 template <typename T>
 __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
                                                                const T* __restrict__ temb,
                                                                const float* __restrict__ wg,
                                                                float* __restrict__ logits, int S, int T_, int n_vis,
                                                                int mode, int M, int E) {
+  __shared__ float red[4][16][64];
   const int lane = lane_id();
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int s0 = wave * 32;
-  if (s0 >= S) return;
+  const int wave = threadIdx.x >> 6;
+  const int s0 = blockIdx.x * 32;
   const int i = lane & 31, hh = lane >> 5;
   const int s = min(s0 + i, S - 1);
+  const int kq = ((M / 16 + 3) / 4) * 16;              // K elements per wave (multiple of 16)
+  const int k_lo = wave * kq, k_hi = min(M, k_lo + kq);
   const T* hp = h + (size_t)s * M;
   const T* emb = nullptr;
   if (mode != EVE_MODE_NONE) emb = token_modality(s, T_, n_vis, mode) ? temb : vemb;
@@ -377,11 +398,11 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   constexpr int KU = 4;  // 16-wide k blocks whose loads are issued together (latency hiding)
-  for (int k0 = 0; k0 < M; k0 += 16 * KU) {
+  for (int k0 = k_lo; k0 < k_hi; k0 += 16 * KU) {
     float a[KU][8], b[KU][8];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      const int k = min(k0 + 16 * u, M - 16) + 8 * hh;  // clamp: blocks past M are masked below
+      const int k = min(k0 + 16 * u, M - 16) + 8 * hh;  // clamp: blocks past the range are masked below
       const Vec16<T> hv0 = load16<T>(hp + k);
       if constexpr (Vec16<T>::N == 8) {
 #pragma unroll
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
           for (int j = 0; j < 4; ++j) { a[u][j] += e0.get(j); a[u][4 + j] += e1.get(j); }
         }
       }
-      const float m = (k0 + 16 * u < M) ? wmask : 0.f;
+      const float m = (k0 + 16 * u < k_hi) ? wmask : 0.f;
       const float4 w0 = *reinterpret_cast<const float4*>(wp + k), w1 = *reinterpret_cast<const float4*>(wp + k + 4);
       b[u][0] = w0.x * m; b[u][1] = w0.y * m; b[u][2] = w0.z * m; b[u][3] = w0.w * m;
       b[u][4] = w1.x * m; b[u][5] = w1.y * m; b[u][6] = w1.z * m; b[u][7] = w1.w * m;
@@ -411,12 +432,18 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc, 0, 0, 0);
   }
-  // D: column (expert) = lane & 31, row (token) = (r & 3) + 8 * (r >> 2) + 4 * hh
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // D: column (expert) = lane & 31, row (token) = (r & 3) + 8 * (r >> 2) + 4 * hh; wave w finishes
+  // registers 4w .. 4w+3
   if (i < E) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 4 + q;
+      const float v = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (s0 + row < S) logits[(size_t)(s0 + row) * E + i] = acc[r];
+      if (s0 + row < S) logits[(size_t)(s0 + row) * E + i] = v;
     }
   }
 }
@@ -502,8 +529,7 @@ template <typename T>
 static int launch_logits(const void* h, const void* ve, const void* te, const float* wg, float* logits, int S, int T_,
                          int n_vis, int mode, int M, int E, hipStream_t st) {
   if (E <= 32 && M % 16 == 0) {
-    const int waves = ceil_div(S, 32);
-    hipLaunchKernelGGL((gate_logits_mfma_kernel<T>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, (const T*)h,
+    hipLaunchKernelGGL((gate_logits_mfma_kernel<T>), dim3(ceil_div(S, 32)), dim3(256), 0, st, (const T*)h,
                        (const T*)ve, (const T*)te, wg, logits, S, T_, n_vis, mode, M, E);
     EVE_CHECK_LAUNCH("gate_logits_mfma_kernel");
     return EVE_OK;
@@ -625,7 +651,7 @@ extern "C" int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const i
 }
 
 static const int kWgradTS = 64;       // VALU kernel
-static const int kWgradMfmaTS = 128;  // fp32-MFMA kernel
+static const int kWgradMfmaTS = 64;   // fp32-MFMA kernel
 static inline bool wgrad_use_mfma(int M, int E) { return E <= 32 && M % 8 == 0 && M <= 1024; }
 
 extern "C" size_t eve_gate_wgrad_workspace_bytes(int S, int M, int E) {
