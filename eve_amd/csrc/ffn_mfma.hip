@@ -19,6 +19,8 @@
 // bias gradient (column sums of the k-major A tile).
 #include "ffn_mfma.h"
 
+#include <cstdlib>
+
 #include "act.h"
 
 namespace eve {
@@ -59,7 +61,25 @@ struct MfmaDesc {
   int Mext, N, K;
   int G, E_local;
   const int32_t* rows;
+#ifdef EVE_PP_STAMP
+  unsigned long long* dbg;  // diagnostic build (tools/pp_stamps.hip): [block 0 / 1000][wave 8][64] cycle stamps (low 32 bits)
+  int same_tile;            // diagnostic: every K step fetches K tile 0 (everything hits in L2)
+#endif
 };
+
+// In-kernel cycle stamps, compiled only into the diagnostic build; they go to a buffer of their own.
+#ifdef EVE_PP_STAMP
+// stamp k of K tile t goes to lane 5t+k of one VGPR (no memory traffic inside the loop); tiles 0..11
+#define EVE_STAMP(k)                                                                                     \
+  do {                                                                                                   \
+    if (t < 12) {                                                                                        \
+      const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime();                                        \
+      stamp_v = lane == t * 5 + (k) ? c_ : stamp_v;                                                      \
+    }                                                                                                    \
+  } while (0)
+#else
+#define EVE_STAMP(k) do { } while (0)
+#endif
 
 // ---- LDS images -------------------------------------------------------------------
 // row-major tile: [W rows][64 k] bf16, 128 B per row, 8 chunks of 16 B
@@ -152,6 +172,88 @@ template <int PER> __device__ __forceinline__ void wait_tiles_in_flight(int tile
   else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Epilogue of one block tile.  Per wave, one 32-row slab (MFMA row tile i) at a time through a private
+// fp32 LDS image, so that global stores are 16 B per lane along rows.  Only the wave itself touches
+// its image; waves are laid out (wave >> 2) x (wave & 3) over 128 x 64 outputs each.
+template <int EPI, int ACT>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WTM][WTN], char* smem, const MfmaDesc& d, int z, int e_out,
+                                              int m0, int n0, int mext, int wave, int lane) {
+  const int wm = wave >> 2, wn = wave & 3;
+  float* ep = reinterpret_cast<float*>(smem) + wave * 32 * EPI_LD;
+  bf16_t* Cg = d.C ? d.C + (size_t)z * d.c_g : nullptr;
+  bf16_t* C2g = d.C2 ? d.C2 + (size_t)z * d.c_g : nullptr;
+  const bf16_t* Zg = d.Zin ? d.Zin + (size_t)z * d.c_g : nullptr;
+  float bv[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    bv[j] = 0.f;
+    if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT)
+      bv[j] = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * 32 + (lane & 31)]);
+  }
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item >> 3, ch = item & 7;
+      const int m = m0 + wm * 128 + i * 32 + row;
+      if (m >= mext) continue;
+      const int n = n0 + wn * 64 + ch * 8;
+      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const size_t o = (size_t)m * d.ldc + n;
+      if constexpr (EPI == MEPI_BIAS_ACT) {
+        if (Cg) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
+        *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
+      } else {
+        if constexpr (EPI == MEPI_DACT) {
+          const uint4 zz = *reinterpret_cast<const uint4*>(Zg + o);
+          const uint32_t* w = &zz.x;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
+        }
+        *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Bias gradient of a weight-gradient tile: reduce the per-thread partial column sums of the k-major
+// A tiles (thread t owns the 8 columns of chunk t % (BM/8)) and store BM values.  Block-uniform call.
+template <int BM, int THREADS>
+__device__ __forceinline__ void bias_grad_store(const float (&bsum)[8], char* smem, const MfmaDesc& d, int z, int m0) {
+  __syncthreads();
+  constexpr int CPR = BM / 8, RG = THREADS / CPR;  // row groups that share a chunk column
+  float* red = reinterpret_cast<float*>(smem);      // [RG][BM]
+  const int c = threadIdx.x % CPR, rg = threadIdx.x / CPR;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rg * BM + c * 8 + j] = bsum[j];
+  __syncthreads();
+  if (threadIdx.x < BM) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) s += red[r * BM + threadIdx.x];
+    d.dbias[(size_t)z * d.Mext + m0 + threadIdx.x] = static_cast<bf16_t>(s);
+  }
+}
+#endif  // __HIP_DEVICE_COMPILE__
 
 template <int BM, int NS, bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD>
 __global__ __launch_bounds__((BM / 128) * 256) void grouped_gemm_mfma(MfmaDesc d) {
@@ -282,25 +384,30 @@ __global__ __launch_bounds__((BM / 128) * 256) void grouped_gemm_mfma(MfmaDesc d
     __builtin_amdgcn_s_barrier();  // tile 0 is in LDS
     if (D < nk) stage(D);
     if constexpr (!WGRAD) {
+      // The last K tile is peeled off: with it inside the loop the two paths into the second MFMA
+      // group join, and the compiler's conservative lgkmcnt waits at the join make that group wait
+      // for the fragment reads just issued for the NEXT half tile.
       read_half(smem, a0, b0, 0);
-      for (int t = 0; t < nk; ++t) {
+      for (int t = 0; t + 1 < nk; ++t) {
         const char* sa = smem + (t % NS) * C_::kStage;
         read_half(sa, a1, b1, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_half(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nk) {
-          // tile t+1 must have landed; tiles t+2 .. t+D (where they exist) may stay in flight
-          wait_tiles_in_flight<C_::kDmaA + C_::kDmaB>(min(D - 1, nk - 2 - t));
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile t are complete
-          __builtin_amdgcn_s_barrier();                       // tile t+1 visible; tile t's stage is free
-          if (t + 1 + D < nk) stage(t + 1 + D);               // into the stage tile t was read from
-          read_half(smem + ((t + 1) % NS) * C_::kStage, a0, b0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        // tile t+1 must have landed; tiles t+2 .. t+D (where they exist) may stay in flight
+        wait_tiles_in_flight<C_::kDmaA + C_::kDmaB>(min(D - 1, nk - 2 - t));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile t are complete
+        __builtin_amdgcn_s_barrier();                       // tile t+1 visible; tile t's stage is free
+        if (t + 1 + D < nk) stage(t + 1 + D);               // into the stage tile t was read from
+        read_half(smem + ((t + 1) % NS) * C_::kStage, a0, b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_half(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      read_half(smem + ((nk - 1) % NS) * C_::kStage, a1, b1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(a0, b0);
+      mfma_half(a1, b1);
     } else {
       // weight-gradient kernels: transposed reads need more address registers, so one fragment
       // set only (no register double buffering) to stay inside 256 registers
@@ -323,82 +430,228 @@ __global__ __launch_bounds__((BM / 128) * 256) void grouped_gemm_mfma(MfmaDesc d
   }
   __syncthreads();  // all fragment reads done before the epilogue reuses LDS
 
-  // ------------------------------------------------------------------ epilogue
-  // Per wave, one 32-row slab (MFMA row tile i) at a time through a private fp32 LDS image, so that
-  // global stores are 16 B per lane along rows.  Only the wave itself touches its image.
-  const int e_out = WGRAD ? z : z % d.E_local;
-  float* ep = reinterpret_cast<float*>(smem) + wave * 32 * EPI_LD;
-  bf16_t* Cg = d.C ? d.C + (size_t)z * d.c_g : nullptr;
-  bf16_t* C2g = d.C2 ? d.C2 + (size_t)z * d.c_g : nullptr;
-  const bf16_t* Zg = d.Zin ? d.Zin + (size_t)z * d.c_g : nullptr;
-  float bv[WTN];
-#pragma unroll
-  for (int j = 0; j < WTN; ++j) {
-    bv[j] = 0.f;
-    if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT)
-      bv[j] = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * 32 + (lane & 31)]);
-  }
-#pragma unroll
-  for (int i = 0; i < WTM; ++i) {
-    const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < WTN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int item = it * 64 + lane;
-      const int row = item >> 3, ch = item & 7;
-      const int m = m0 + wm * 128 + i * 32 + row;
-      if (m >= mext) continue;
-      const int n = n0 + wn * 64 + ch * 8;
-      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8);
-      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8 + 4);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const size_t o = (size_t)m * d.ldc + n;
-      if constexpr (EPI == MEPI_BIAS_ACT) {
-        if (Cg) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
-        *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
-      } else {
-        if constexpr (EPI == MEPI_DACT) {
-          const uint4 zz = *reinterpret_cast<const uint4*>(Zg + o);
-          const uint32_t* w = &zz.x;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
-        }
-        *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-
+  tile_epilogue<EPI, ACT>(acc, smem, d, z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
   if constexpr (BIAS_GRAD) {
-    if (do_bias_grad) {  // block-uniform
-      __syncthreads();
-      constexpr int CPR = BM / 8, RG = C_::kThreads / CPR;  // row groups that share a chunk column
-      float* red = reinterpret_cast<float*>(smem);           // [RG][BM]
-      const int c = threadIdx.x % CPR, rg = threadIdx.x / CPR;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) red[rg * BM + c * 8 + j] = bsum[j];
-      __syncthreads();
-      if (threadIdx.x < BM) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < RG; ++r) s += red[r * BM + threadIdx.x];
-        d.dbias[(size_t)z * d.Mext + m0 + threadIdx.x] = static_cast<bf16_t>(s);
-      }
-    }
+    if (do_bias_grad) bias_grad_store<BM, C_::kThreads>(bsum, smem, d, z, m0);  // block-uniform
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
+
+// ------------------------------------------------------------------ ping-pong kernel
+// 256 x 256 block tile, 8 waves; the two waves of every SIMD (wave w and w + 4) run half a K step
+// apart, so that while one of them issues its 32 MFMAs of a K step ("M" phase, operands already in
+// registers) its partner issues its LDS-DMAs and fragment reads for the next one ("L" phase): the
+// matrix pipe of a SIMD always has one wave feeding it and the other wave's memory instructions,
+// which an in-order wave cannot overlap with its own MFMAs, run beside them.  Workgroup barriers
+// separate the phases (intervals I_0, I_1, ...):
+//     waves 0-3:  L(0) | M(0) | L(1) | M(1) | ...
+//     waves 4-7:   -   | L(0) | M(0) | L(1) | M(1) ...
+// Operand tiles live in a ring of five 256 x BKI sub-tiles (160 KiB at BKI = 64, all of the CU's
+// LDS): sub-tile 2t is A(t), 2t+1 is B(t).  Waves 0-3 fetch B(t+1) during L(t) (interval 2t) and
+// wait for it at the end of M(t); waves 4-7 fetch A(t+2) during their L(t) (interval 2t+1) and wait
+// at the end of their M(t).  A slot is rewritten only after the barrier that ends the interval in
+// which the later half read its previous tenant (every L phase ends with lgkmcnt(0) + barrier),
+// and every fetch has more than a whole interval to land before anyone needs it.
+// Per-lane source offset (bytes) of a wave's first DMA piece of a sub-tile; piece i of the wave lies
+// sub_dma_stride() bytes * i further on (the chunk swizzle repeats with that period), which keeps the
+// per-piece part of the address wave-uniform.
+template <bool COL, int BKI>
+__device__ __forceinline__ uint32_t sub_dma_offset0(int ld, int w4, int lane) {
+  const int P = w4 * 64 + lane;
+  int row, c;
+  if constexpr (COL) {
+    row = P >> 5;                       // 32 chunks per k-row of 256 columns; 8 k-rows per 4 pieces
+    c = (P & 31) ^ ((row & 3) << 2);
+  } else {
+    static_assert(COL || BKI == 64, "row-major sub-tiles are 64 deep");
+    row = P >> 3;                       // 8 chunks per row; 32 rows per 4 pieces
+    c = (P & 7) ^ ((row >> 1) & 7);
+  }
+  return ((uint32_t)row * (uint32_t)ld + (uint32_t)c * 8u) * 2u;
+}
+template <bool COL> __device__ __forceinline__ uint32_t sub_dma_stride(int ld) { return (uint32_t)(COL ? 8 : 32) * (uint32_t)ld * 2u; }
+
+template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI>
+__global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaDesc d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, KI = BKI / 16, NSLOT = 5;
+  constexpr int kSub = 256 * BKI * 2;       // bytes of one sub-tile
+  constexpr int NP = kSub / 1024 / 4;       // DMA instructions per wave per sub-tile
+  static_assert(NP % KI == 0, "DMA pieces interleave evenly with the k16 steps");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int h = wave_u >> 2, w4 = wave_u & 3;  // half (= row half of the tile), index inside the half
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-aware tile order (see grouped_gemm_mfma)
+  const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
+  const int tiles_per_group = tiles_m * tiles_n;
+  const int ngroups = WGRAD ? d.E_local : d.G;
+  const int chunk = (ngroups + 7) >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int p = xcd * chunk + local / tiles_per_group;
+  if (p >= ngroups) return;
+  const int tile = local % tiles_per_group;
+  int z;
+  if (WGRAD) {
+    z = p;
+  } else {
+    const int ep = d.G / d.E_local;
+    z = (p % ep) * d.E_local + p / ep;
+  }
+  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+  int mext = d.Mext;
+  if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
+  if (m0 >= mext) return;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+  const bool do_bias_grad = BIAS_GRAD && n0 == 0;
+#ifdef EVE_PP_STAMP
+  uint32_t stamp_v = 0;
+  { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 62 ? c_ : stamp_v; }
+#endif
+
+  // waves 0-3 only ever fetch B tiles, waves 4-7 only A tiles
+  const uint32_t voff0 = h == 0 ? sub_dma_offset0<B_COL, BKI>(d.ldb, w4, lane) : sub_dma_offset0<A_COL, BKI>(d.lda, w4, lane);
+  const uint32_t vstride = h == 0 ? sub_dma_stride<B_COL>(d.ldb) : sub_dma_stride<A_COL>(d.lda);
+
+  const int nseg = WGRAD ? d.G / d.E_local : 1;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const int g = WGRAD ? seg * d.E_local + z : z;
+    const int e = WGRAD ? z : z % d.E_local;
+    int kext = d.K;
+    if (WGRAD && d.rows) kext = min(kext, d.rows[g]);
+    const int nk = (kext + BKI - 1) / BKI;
+    if (nk == 0) continue;
+    const bf16_t* Ag = d.A + (size_t)g * d.a_g;
+    const bf16_t* Bg = d.B + (size_t)(WGRAD ? g : e) * d.b_g;
+    const uint32_t a_bytes = (uint32_t)(A_COL ? (WGRAD ? kext : d.K) * d.lda : d.Mext * d.lda) * 2u;
+    const uint32_t b_bytes = (uint32_t)(B_COL ? (WGRAD ? kext : d.K) * d.ldb : d.N * d.ldb) * 2u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bg), 0, b_bytes, 0x00020000);
+    // my operand's K tile t: origin inside the operand, and its ring slot
+    auto my_origin = [&](int t) -> uint32_t {
+#ifdef EVE_PP_STAMP
+      if (d.same_tile) t = 0;
+#endif
+      if (h == 0) return (uint32_t)(B_COL ? (t * BKI) * d.ldb + n0 : n0 * d.ldb + t * BKI) * 2u;
+      return (uint32_t)(A_COL ? (t * BKI) * d.lda + m0 : m0 * d.lda + t * BKI) * 2u;
+    };
+    auto my_slot = [&](int t) -> char* { return smem + ((2 * t + (h == 0 ? 1 : 0)) % NSLOT) * kSub; };  // prologue only
+    auto dma_piece = [&](char* slot, uint32_t origin, int i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(h == 0 ? b_rsrc : a_rsrc,
+                                               (__attribute__((address_space(3))) void*)(slot + (i * 4 + w4) * 1024), 16,
+                                               voff0 + (origin + (uint32_t)i * vstride), 0, 0, 0);
+    };
+
+    bf16x8 fa[KI][WTM], fb[KI][WTN];
+    // L phase: fragment reads of tile t, interleaved with the DMA pieces of the tile fetched now
+    auto load_phase = [&](int sl_a, bool fetch, int tf) {
+      const int sl_b = sl_a + 1 >= NSLOT ? sl_a + 1 - NSLOT : sl_a + 1;
+      // B(t+1) goes 2 slots past B(t); A(t+2) goes 4 slots past A(t)
+      const int sl_f = h == 0 ? (sl_b + 2 >= NSLOT ? sl_b + 2 - NSLOT : sl_b + 2) : (sl_a + 4 >= NSLOT ? sl_a + 4 - NSLOT : sl_a + 4);
+      const char* sa = smem + sl_a * kSub;
+      const char* sb = smem + sl_b * kSub;
+      char* slot = smem + sl_f * kSub;
+      const uint32_t origin = my_origin(tf);
+#pragma unroll
+      for (int ks = 0; ks < KI; ++ks) {
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[ks][j] = frag_load<B_COL, BN>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[ks][i] = frag_load<A_COL, BM>(sa, wm * 128 + i * 32, ks, lane);
+      }
+      if constexpr (BIAS_GRAD) {
+        if (do_bias_grad) {  // column sums of the k-major A tile, read back from LDS
+#pragma unroll
+          for (int i = 0; i < kSub / 16 / 512; ++i) {
+            const int idx = threadIdx.x + 512 * i;
+            const uint4 v = *reinterpret_cast<const uint4*>(sa + col_tile_off<BM>(idx >> 5, idx & 31));
+            const uint32_t* w = &v.x;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += bf16_bits_to_f32(w[j >> 1], j & 1);
+          }
+        }
+      }
+      // The fetch is issued after the reads: the compiler puts a vmcnt(0) in front of a transposed LDS
+      // read that follows an LDS-DMA in program order, which would make the wave wait for its own fetch.
+      if (fetch) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) dma_piece(slot, origin, i);
+      }
+    };
+
+    // prologue: A(0), A(1) by waves 4-7, B(0) by waves 0-3
+    {
+      char* s0 = my_slot(0);
+      const uint32_t o0 = my_origin(0);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) dma_piece(s0, o0, i);
+      if (h == 1 && nk > 1) {
+        char* s1 = my_slot(1);
+        const uint32_t o1 = my_origin(1);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) dma_piece(s1, o1, i);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (h == 1) __builtin_amdgcn_s_barrier();  // interval 0: waves 4-7 have nothing to do yet
+    int sl_a = 0;  // ring slot of A(t); B(t) is the next one
+    for (int t = 0; t < nk; ++t) {
+      const int tf = t + 1 + h;  // waves 0-3 fetch B(t+1), waves 4-7 fetch A(t+2)
+      EVE_STAMP(0);
+      load_phase(sl_a, tf < nk, tf);
+      sl_a = sl_a + 2 >= NSLOT ? sl_a + 2 - NSLOT : sl_a + 2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      EVE_STAMP(1);
+      __builtin_amdgcn_s_barrier();
+      EVE_STAMP(2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KI; ++ks)
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      EVE_STAMP(3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my fetch has landed (it had the whole M phase)
+      EVE_STAMP(4);
+      // no barrier after the last M phase of waves 4-7: nobody reads or writes the ring any more, and
+      // waves 0-3 (one barrier ahead) go straight on to their epilogue / next segment
+      if (!(h == 1 && t == nk - 1)) __builtin_amdgcn_s_barrier();
+    }
+  }
+  // The ring is dead from here on (all reads and fetches completed before the last barrier each wave
+  // passed), so each wave may overwrite its own epilogue image without another barrier.
+#ifdef EVE_PP_STAMP
+  { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 60 ? c_ : stamp_v; }
+#endif
+  tile_epilogue<EPI, ACT>(acc, smem, d, z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+  if constexpr (BIAS_GRAD) {
+    if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, z, m0);  // block-uniform
+  }
+#ifdef EVE_PP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 61 ? c_ : stamp_v; }
+  if (d.dbg && (blockIdx.x == 0 || blockIdx.x == 1000)) d.dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_v;
+#endif
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
 
 bool ffn_mfma_supported(int M, int I) { return M % 256 == 0 && I % 256 == 0; }
 
@@ -439,12 +692,57 @@ static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
   return EVE_OK;
 }
 
-// Tile choice: 256 x 256 tiles (8 waves) unless the row extent is small enough that a 256-row
-// tile would be mostly padding (then 128 x 256 tiles, 4 waves).
+template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI>
+static int launch_pp(const MfmaDesc& d, int act, hipStream_t st) {
+  constexpr int kEpi = 8 * 32 * EPI_LD * 4;
+  constexpr int kLds = 5 * 256 * BKI * 2 > kEpi ? 5 * 256 * BKI * 2 : kEpi;
+  const int ngroups = WGRAD ? d.E_local : d.G;
+  dim3 grid(8 * ceil_div(ngroups, 8) * (d.N / BN) * ceil_div(d.Mext, 256));
+#define EVE_PP_LAUNCH(A)                                                                                     \
+  do {                                                                                                       \
+    auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI>;                                \
+    static bool attr_done = false;                                                                           \
+    if (!attr_done) {                                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              kLds) != hipSuccess) {                                                         \
+        set_error("ffn_mfma: cannot reserve %d bytes of LDS", kLds);                                         \
+        return EVE_ERR_LAUNCH;                                                                               \
+      }                                                                                                      \
+      attr_done = true;                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, d);                                                  \
+  } while (0)
+  if constexpr (EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT) {
+    switch (act) {
+      case EVE_ACT_QUICK_GELU: EVE_PP_LAUNCH(EVE_ACT_QUICK_GELU); break;
+      case EVE_ACT_GELU: EVE_PP_LAUNCH(EVE_ACT_GELU); break;
+      case EVE_ACT_RELU: EVE_PP_LAUNCH(EVE_ACT_RELU); break;
+      case EVE_ACT_IDENTITY: EVE_PP_LAUNCH(EVE_ACT_IDENTITY); break;
+      default:
+        set_error("ffn_mfma: unknown activation %d", act);
+        return EVE_ERR_ARG;
+    }
+  } else {
+    EVE_PP_LAUNCH(EVE_ACT_IDENTITY);
+  }
+#undef EVE_PP_LAUNCH
+  EVE_CHECK_LAUNCH("grouped_gemm_pp");
+  return EVE_OK;
+}
+
+// Debug knob for A/B timing: EVE_FFN_KERNEL=lockstep selects the older 256-row kernel.
+static bool use_pingpong() {
+  const char* v = getenv("EVE_FFN_KERNEL");
+  return !(v && v[0] == 'l');
+}
+
+// Tile choice: 256 x 256 tiles (8 waves, ping-pong schedule) unless the row extent is small enough
+// that a 256-row tile would be mostly padding (then 128 x 256 tiles, 4 waves).
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
 static int launch(const MfmaDesc& d, int act, hipStream_t st) {
   const bool small = !WGRAD && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024));
   if (small) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
+  if (use_pingpong()) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, (A_COL && B_COL) ? 32 : 64>(d, act, st);
   return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
 }
 

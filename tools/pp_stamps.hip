@@ -1,0 +1,69 @@
+// Diagnostic build of the ping-pong grouped GEMM with in-kernel cycle stamps (s_memtime) around the
+// L / M phases of the first K tiles of two workgroups.  Not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Ieve_amd/csrc -DEVE_PP_STAMP \
+//         tools/pp_stamps.hip eve_amd/csrc/capi.hip -o tools/pp_stamps
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../eve_amd/csrc/ffn_mfma.hip"
+
+using namespace eve;
+
+template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BG, int BKI>
+static void run(const char* name, int G, int R, int N, int K, bool bcol, int same_tile = 0) {
+  const size_t na = (size_t)G * R * K, nb = (size_t)G * N * K, nc = (size_t)G * R * N;
+  std::vector<unsigned short> ha(na), hb(nb);
+  srand(1);
+  for (auto& v : ha) v = 0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15);  // random bf16 around +-1
+  for (auto& v : hb) v = 0x3a00 + (rand() & 0x3ff) + ((rand() & 1) << 15);
+  bf16_t *A, *B, *C, *bias, *Z;
+  unsigned long long* dbg;
+  hipMalloc(&A, na * 2); hipMalloc(&B, nb * 2); hipMalloc(&C, nc * 2); hipMalloc(&Z, nc * 2); hipMalloc(&bias, (size_t)G * N * 2);
+  hipMalloc(&dbg, 2 * 8 * 64 * 8);
+  hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice);
+  hipMemcpy(B, hb.data(), nb * 2, hipMemcpyHostToDevice);
+  hipMemset(bias, 0, (size_t)G * N * 2); hipMemset(Z, 0, nc * 2);
+  MfmaDesc d{};
+  d.G = G; d.E_local = G; d.rows = nullptr; d.Mext = R;
+  d.A = A; d.a_g = (long)R * K; d.lda = K;
+  d.B = B; d.b_g = (long)N * K; d.ldb = bcol ? N : K;
+  d.C = C; d.C2 = C; d.c_g = (long)R * N; d.ldc = N; d.bias = bias; d.Zin = Z; d.N = N; d.K = K;
+  d.dbg = nullptr; d.same_tile = same_tile;
+  for (int i = 0; i < 20; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI>(d, EVE_ACT_QUICK_GELU, 0);
+  hipDeviceSynchronize();
+  hipMemset(dbg, 0, 2 * 8 * 64 * 8);
+  d.dbg = dbg;
+  launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI>(d, EVE_ACT_QUICK_GELU, 0);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(2 * 8 * 64);
+  hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+  printf("== %s  G=%d R=%d N=%d K=%d (%s)\n", name, G, R, N, K, hipGetErrorString(hipGetLastError()));
+  for (int b = 0; b < 1; ++b)
+    for (int w = 0; w < 8; w += 4) {
+      printf("block %d wave %d: per tile  L(reads+dma+lgkm0) | barrier | M(issue) | vmcnt0 | barrier   [start rel. wave0 tile0]\n", b ? 1000 : 0, w);
+      const unsigned long long* base0 = &h[(b * 8 + 0) * 64];
+      {
+        const unsigned long long* s = &h[(b * 8 + w) * 64];
+        auto df = [](unsigned long long x, unsigned long long y) { return (long long)(int)((unsigned)x - (unsigned)y); };
+        printf("   kernel start -> first L phase %lld ; epilogue (incl. store drain) %lld ; whole wave %lld\n", df(s[0], s[62]), df(s[61], s[60]), df(s[61], s[62]));
+      }
+      for (int t = 3; t < 6; ++t) {
+        const unsigned long long* s = &h[(b * 8 + w) * 64 + t * 5];
+        const unsigned long long* n = s + 5;
+        auto df = [](unsigned long long x, unsigned long long y) { return (long long)(int)((unsigned)x - (unsigned)y); };
+        printf("   t=%2d  %6lld %6lld %6lld %6lld %6lld   [%lld]\n", t, df(s[1], s[0]), df(s[2], s[1]), df(s[3], s[2]),
+               df(s[4], s[3]), df(n[0], s[4]), df(s[0], base0[0]));
+      }
+    }
+  hipFree(A); hipFree(B); hipFree(C); hipFree(Z); hipFree(bias); hipFree(dbg);
+}
+
+int main() {
+  run<false, false, MEPI_BIAS, false, false, 64>("fwd2  (row,row) N=768 K=3072", 32, 948, 768, 3072, false);
+  run<false, false, MEPI_BIAS, false, false, 64>("fwd2  SAME TILE (all L2 hits)", 32, 948, 768, 3072, false, 1);
+  run<false, true, MEPI_STORE, false, false, 64>("dgrad1 (row,col) N=768 K=3072", 32, 948, 768, 3072, true);
+  run<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1  (row,row) N=3072 K=768", 32, 948, 3072, 768, false);
+  run<false, true, MEPI_DACT, false, false, 64>("dgrad2 (row,col) N=3072 K=768", 32, 948, 3072, 768, true);
+  return 0;
+}
