@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--model", default="base", choices=["base", "large"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -120,12 +121,23 @@ def main():
     dout = torch.randn(B, T, M, generator=g).to(dtype).to(dev)
     params = [p for p in moe.parameters()]
 
-    def step():
+    def eager_step():
         for p in params:
             p.grad = None
         x = h.detach().requires_grad_(True)
         out, l_aux, _ = moe(x, mode="vl")
         torch.autograd.backward([out, l_aux], [dout, torch.ones_like(l_aux)])
+
+    # One step is ~50 launches; issued from Python the host is slower than the GPU, so on one GPU the
+    # step (noise draw, forward, full backward) is captured once into a HIP graph and replayed.  With
+    # expert parallelism the step contains RCCL all-to-alls and is issued eagerly.
+    use_graph = world == 1 and not args.no_graph
+    if use_graph:
+        import eve_amd
+        graphed = eve_amd.GraphedTrainStep(moe, h, dout, mode="vl")
+        step = lambda: graphed(h, dout)
+    else:
+        step = eager_step
 
     def sync():
         torch.cuda.synchronize()
@@ -136,17 +148,24 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    ops.PROFILE.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    prof = ops.PROFILE.disable()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # Per-kernel HIP-event timing (on the launch stream) of the same K steps, issued eagerly right after
+    # the timed region: events cannot be recorded inside a graph replay.  Kernel durations are the
+    # same in both modes (profiles/ holds the rocprofv3 trace of this command).
+    ops.PROFILE.enable()
+    for _ in range(args.steps):
+        eager_step()
+    sync()
+    prof = ops.PROFILE.disable()
 
     # kept assignments of the last step (exact K for the algorithmic flop count)
     kept = int((moe.moe.last_slot >= 0).sum().item())
@@ -171,7 +190,8 @@ def main():
             "config": {"workload": f"EVE-{args.model} modality-aware MoE layer fwd+bwd (BASELINE configs[1] layer shape): "
                                    f"B={B}/GPU x ({n_vis} vision + {args.text_tokens} text) tokens, M={M}, I={I}, E={E} top-2, "
                                    f"capacity_factor 1.0, mode vl", "tokens_per_gpu": S, "kept_assignments": kept,
-                       "parallelism": f"ep{world}" if world > 1 else "single"},
+                       "parallelism": f"ep{world}" if world > 1 else "single",
+                       "launch": "hipgraph replay of the whole step" if use_graph else "eager, one launch per kernel"},
             "roofline": roofline,
             "phases_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }

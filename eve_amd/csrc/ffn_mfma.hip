@@ -192,8 +192,26 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WTM][WTN], cha
     if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT)
       bv[j] = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * 32 + (lane & 31)]);
   }
+  // item `it` of a slab: lane -> (row it*8 + lane/8, 8 columns from (lane%8)*8)
+  const int irow = lane >> 3, ich = lane & 7;
+  const int ncol = n0 + wn * 64 + ich * 8;
+  // DACT reads the saved pre-activation z: the loads of slab i+1 are issued before slab i is worked
+  // on, so that their latency is paid once per tile, not once per item.  Rows past the extent are
+  // clamped for the load (their results are never stored).
+  uint4 zbuf[2][4];
+  auto load_z = [&](int i, uint4 (&dst)[4]) {
+    if constexpr (EPI == MEPI_DACT) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = min(m0 + wm * 128 + i * 32 + it * 8 + irow, mext - 1);
+        dst[it] = *reinterpret_cast<const uint4*>(Zg + (size_t)m * d.ldc + ncol);
+      }
+    }
+  };
+  load_z(0, zbuf[0]);
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
+    if (i + 1 < WTM) load_z(i + 1, zbuf[(i + 1) & 1]);
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int j = 0; j < WTN; ++j)
@@ -206,28 +224,24 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WTM][WTN], cha
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int item = it * 64 + lane;
-      const int row = item >> 3, ch = item & 7;
+      const int row = it * 8 + irow;
       const int m = m0 + wm * 128 + i * 32 + row;
-      if (m >= mext) continue;
-      const int n = n0 + wn * 64 + ch * 8;
-      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8);
-      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ch * 8 + 4);
+      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8 + 4);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const size_t o = (size_t)m * d.ldc + n;
+      const size_t o = (size_t)m * d.ldc + ncol;
       if constexpr (EPI == MEPI_BIAS_ACT) {
-        if (Cg) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+        if (Cg && m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
-        *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
+        if (m < mext) *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
       } else {
         if constexpr (EPI == MEPI_DACT) {
-          const uint4 zz = *reinterpret_cast<const uint4*>(Zg + o);
-          const uint32_t* w = &zz.x;
+          const uint32_t* w = &zbuf[i & 1][it].x;
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
         }
-        *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+        if (m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

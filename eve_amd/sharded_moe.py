@@ -368,9 +368,24 @@ def _accepts_rows(experts: nn.Module) -> bool:
     return getattr(experts, "accepts_rows", False)
 
 
+_graph_host_counts: Dict[Tuple[int, ...], Tensor] = {}
+
+
 def _host_counts(exp_counts: Tensor, blocking: bool) -> Tensor:
+    if torch.cuda.is_current_stream_capturing():
+        # under HIP-graph capture nothing may be allocated on the host: the copy node targets one
+        # pinned buffer per shape, refilled by every replay (eve_amd.graph.GraphedTrainStep)
+        key = tuple(exp_counts.shape)
+        host = _graph_host_counts.get(key)
+        if host is None:
+            raise RuntimeError("eve_amd: run the layer once eagerly before capturing it into a graph")
+        host.copy_(exp_counts, non_blocking=True)
+        return host
     if blocking:
         return exp_counts.to("cpu")
     host = torch.empty(exp_counts.shape, dtype=exp_counts.dtype, pin_memory=True)
     host.copy_(exp_counts, non_blocking=True)
+    key = tuple(exp_counts.shape)
+    if key not in _graph_host_counts:
+        _graph_host_counts[key] = torch.empty(exp_counts.shape, dtype=exp_counts.dtype, pin_memory=True)
     return host
