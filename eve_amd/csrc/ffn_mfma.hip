@@ -67,6 +67,11 @@ struct MfmaDesc {
 #endif
 };
 
+struct MfmaPair {
+  MfmaDesc d[2];
+  int n0;  // blocks of d[0]; a multiple of 8 (the XCD-aware tile order counts from each problem's first block)
+};
+
 // In-kernel cycle stamps, compiled only into the diagnostic build; they go to a buffer of their own.
 #ifdef EVE_PP_STAMP
 // stamp k of K tile t goes to lane 5t+k of one VGPR (no memory traffic inside the loop); tiles 0..11
@@ -486,8 +491,14 @@ __device__ __forceinline__ uint32_t sub_dma_offset0(int ld, int w4, int lane) {
 template <bool COL> __device__ __forceinline__ uint32_t sub_dma_stride(int ld) { return (uint32_t)(COL ? 8 : 32) * (uint32_t)ld * 2u; }
 
 template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI>
-__global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaDesc d) {
+__global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  // Two independent problems of the same kind may share a launch (the two weight-gradient GEMMs of a
+  // backward pass): blocks [0, n0) work on the first, the rest on the second, so that the tail of the
+  // first one's last wave of tiles is filled by the second instead of leaving CUs idle.
+  const bool second = blockIdx.x >= (unsigned)pr.n0;
+  const MfmaDesc& d = pr.d[second ? 1 : 0];
+  const unsigned bid = second ? blockIdx.x - (unsigned)pr.n0 : blockIdx.x;
   constexpr int BM = 256, KI = BKI / 16, NSLOT = 5;
   constexpr int kSub = 256 * BKI * 2;       // bytes of one sub-tile
   constexpr int NP = kSub / 1024 / 4;       // DMA instructions per wave per sub-tile
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaDesc d) {
   const int tiles_per_group = tiles_m * tiles_n;
   const int ngroups = WGRAD ? d.E_local : d.G;
   const int chunk = (ngroups + 7) >> 3;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int xcd = bid & 7, local = bid >> 3;
   const int p = xcd * chunk + local / tiles_per_group;
   if (p >= ngroups) return;
   const int tile = local % tiles_per_group;
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaDesc d) {
 #ifdef EVE_PP_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 61 ? c_ : stamp_v; }
-  if (d.dbg && (blockIdx.x == 0 || blockIdx.x == 1000)) d.dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_v;
+  if (d.dbg && (bid == 0 || bid == 1000)) d.dbg[((bid ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_v;
 #endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -707,11 +718,18 @@ static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
 }
 
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI>
-static int launch_pp(const MfmaDesc& d, int act, hipStream_t st) {
+static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc* d2 = nullptr) {
   constexpr int kEpi = 8 * 32 * EPI_LD * 4;
   constexpr int kLds = 5 * 256 * BKI * 2 > kEpi ? 5 * 256 * BKI * 2 : kEpi;
-  const int ngroups = WGRAD ? d.E_local : d.G;
-  dim3 grid(8 * ceil_div(ngroups, 8) * (d.N / BN) * ceil_div(d.Mext, 256));
+  auto blocks = [](const MfmaDesc& q) {
+    const int ngroups = WGRAD ? q.E_local : q.G;
+    return 8 * ceil_div(ngroups, 8) * (q.N / BN) * ceil_div(q.Mext, 256);
+  };
+  MfmaPair pr;
+  pr.d[0] = d;
+  pr.d[1] = d2 ? *d2 : d;
+  pr.n0 = blocks(d);
+  dim3 grid(pr.n0 + (d2 ? blocks(*d2) : 0));
 #define EVE_PP_LAUNCH(A)                                                                                     \
   do {                                                                                                       \
     auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI>;                                \
@@ -724,7 +742,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st) {
       }                                                                                                      \
       attr_done = true;                                                                                      \
     }                                                                                                        \
-    hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, d);                                                  \
+    hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, pr);                                                 \
   } while (0)
   if constexpr (EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT) {
     switch (act) {
@@ -797,13 +815,15 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   d.A = (const bf16_t*)dy; d.a_g = (long)R * M; d.lda = M;
   d.B = (const bf16_t*)a; d.b_g = (long)R * I; d.ldb = I;
   d.C = (bf16_t*)dw2; d.c_g = (long)M * I; d.ldc = I; d.N = I; d.K = R; d.dbias = (bf16_t*)db2;
-  if (int rc = launch<true, true, MEPI_STORE, true, true>(d, act, st)) return rc;
   // dw1[e] = sum_g dz[g]^T @ x[g]  ([I,M]);  db1[e] = column sums of dz
-  d.Mext = I;
-  d.A = (const bf16_t*)dz; d.a_g = (long)R * I; d.lda = I;
-  d.B = (const bf16_t*)x; d.b_g = (long)R * M; d.ldb = M;
-  d.C = (bf16_t*)dw1; d.c_g = (long)I * M; d.ldc = M; d.N = M; d.K = R; d.dbias = (bf16_t*)db1;
-  return launch<true, true, MEPI_STORE, true, true>(d, act, st);
+  MfmaDesc d1 = d;
+  d1.Mext = I;
+  d1.A = (const bf16_t*)dz; d1.a_g = (long)R * I; d1.lda = I;
+  d1.B = (const bf16_t*)x; d1.b_g = (long)R * M; d1.ldb = M;
+  d1.C = (bf16_t*)dw1; d1.c_g = (long)I * M; d1.ldc = M; d1.N = M; d1.K = R; d1.dbias = (bf16_t*)db1;
+  if (use_pingpong()) return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, &d1);  // one launch for both
+  if (int rc = launch<true, true, MEPI_STORE, true, true>(d, act, st)) return rc;
+  return launch<true, true, MEPI_STORE, true, true>(d1, act, st);
 }
 
 }  // namespace eve
