@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p, c_long
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeve_moe.so")
@@ -28,6 +28,7 @@ SIGNATURES = {
     "eve_gate_logits_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eve_gate_workspace_bytes": (c_size_t, [_I, _I]),
     "eve_gate_top2_fwd": (c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "eve_gumbel_from_uniform": (c_int, [_P, _P, c_long, _P]),
     "eve_gate_top2_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "eve_gate_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "eve_gate_wgrad": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),

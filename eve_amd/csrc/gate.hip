@@ -583,6 +583,33 @@ static GateWs gate_ws_layout(int S, int E) {
 
 using namespace eve;
 
+// ---- Gumbel(0,1) noise from standard-uniform draws -----------------------------------------------
+// The reference draws torch.distributions.Gumbel(0,1).rsample (sharded_moe.py:70-77,:186), which torch
+// evaluates as ~10 elementwise kernels over one torch.rand() draw: u = tiny + r * ((1 - eps) - tiny),
+// then 0 + (-1) * log(0 + (-1) * log(u)), every step rounded to fp32.  This is the same arithmetic, in
+// the same order and without contraction, in one pass.
+__global__ void gumbel_from_uniform_kernel(const float* __restrict__ r, float* __restrict__ out, long n) {
+  const float low = 1.17549435e-38f;                 // finfo(float32).tiny
+  const float high = 1.0f - 1.1920928955078125e-07f;  // 1 - finfo(float32).eps
+  const float span = __fsub_rn(high, low);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u = __fadd_rn(low, __fmul_rn(r[i], span));
+    const float a = __fadd_rn(0.f, __fmul_rn(-1.f, logf(u)));
+    out[i] = __fadd_rn(0.f, __fmul_rn(-1.f, logf(a)));
+  }
+}
+
+extern "C" int eve_gumbel_from_uniform(const float* uniform, float* noise, long n, void* stream) {
+  EVE_REQUIRE(uniform && noise, EVE_ERR_ARG, "eve_gumbel_from_uniform: null pointer");
+  EVE_REQUIRE(n > 0, EVE_ERR_ARG, "eve_gumbel_from_uniform: n=%ld", n);
+  const int block = 256;
+  const long want = (n + block - 1) / block;
+  const int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(gumbel_from_uniform_kernel, dim3(grid), dim3(block), 0, S_(stream), uniform, noise, n);
+  EVE_CHECK_LAUNCH("gumbel_from_uniform_kernel");
+  return EVE_OK;
+}
+
 extern "C" int eve_gate_logits_fwd(const void* h, const void* vision_embed, const void* text_embed, const float* wg,
                                    float* logits, int S, int T, int n_vis, int mode, int M, int E, int dtype,
                                    void* stream) {

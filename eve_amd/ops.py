@@ -115,6 +115,14 @@ def gate_logits(h2d: torch.Tensor, vemb, temb, wg: torch.Tensor, T: int, n_vis: 
     return logits
 
 
+def gumbel_from_uniform(u: torch.Tensor) -> torch.Tensor:
+    """Gumbel(0,1) variates of standard-uniform draws, torch.distributions.Gumbel's arithmetic in one kernel."""
+    _chk(u, "uniform", torch.float32)
+    out = torch.empty_like(u)
+    PROFILE.call("eve_gumbel_from_uniform", _p(u), _p(out), u.numel(), _stream())
+    return out
+
+
 def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int) -> Routing:
     _chk(logits, "logits", torch.float32), _chk(noise, "noise", torch.float32)
     S, E = logits.shape

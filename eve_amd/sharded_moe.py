@@ -25,17 +25,57 @@ def trunc_normal_(tensor: Tensor, mean: float = 0.0, std: float = 1.0) -> Tensor
     return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=-std, b=std)
 
 
-def gumbel_rsample(shape, device: torch.device) -> Tensor:
-    """One Gumbel(0,1) draw of `shape` from the GLOBAL torch generator of `device`, exactly
-    the call the reference makes (sharded_moe.py:70-77), so RNG consumption -- and hence
-    activation-checkpoint replay -- is unchanged."""
-    device = torch.device(device)
+def _torch_gumbel(shape, device: torch.device) -> Tensor:
     sampler = gumbel_map.get(device)
     if sampler is None:
         sampler = torch.distributions.gumbel.Gumbel(torch.tensor(0.0, device=device),
                                                     torch.tensor(1.0, device=device)).rsample
         gumbel_map[device] = sampler
     return sampler(shape)
+
+
+_fused_gumbel_ok: Dict[torch.device, bool] = {}
+
+
+def _fused_gumbel_matches_torch(device: torch.device) -> bool:
+    """One-time check per device that the one-pass kernel reproduces torch's sampler bit for bit
+    (same generator state in, same fp32 values out); routing parity with the reference rests on it."""
+    gen_state = torch.cuda.get_rng_state(device)
+    try:
+        want = _torch_gumbel((4096,), device)
+        torch.cuda.set_rng_state(gen_state, device)
+        got = ops.gumbel_from_uniform(torch.rand(4096, dtype=torch.float32, device=device))
+        edge = torch.tensor([0.0, 1.0 - 2.0 ** -24, 2.0 ** -24, 0.5], dtype=torch.float32, device=device)
+        tiny, eps = torch.finfo(torch.float32).tiny, torch.finfo(torch.float32).eps
+        u = tiny + edge * ((1.0 - eps) - tiny)
+        want_edge = 0.0 + -1.0 * torch.log(0.0 + -1.0 * torch.log(u))
+        return bool(torch.equal(want, got)) and bool(torch.equal(want_edge, ops.gumbel_from_uniform(edge)))
+    finally:
+        torch.cuda.set_rng_state(gen_state, device)
+
+
+def gumbel_rsample(shape, device: torch.device) -> Tensor:
+    """One Gumbel(0,1) draw of `shape` from the GLOBAL torch generator of `device`, value for value the
+    draw the reference makes (sharded_moe.py:70-77): the same single `torch.rand` consumption of the
+    generator -- so activation-checkpoint RNG replay is unchanged -- followed by the distribution's
+    transform chain, which runs here as one HIP kernel instead of ten elementwise ones.  The kernel is
+    checked once per device against torch's own sampler; should it ever differ, torch's is used."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return _torch_gumbel(shape, device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    ok = _fused_gumbel_ok.get(device)
+    if ok is None:
+        if torch.cuda.is_current_stream_capturing():
+            return _torch_gumbel(shape, device)
+        ok = _fused_gumbel_ok[device] = _fused_gumbel_matches_torch(device)
+        if not ok:
+            import warnings
+            warnings.warn("eve_amd: fused Gumbel kernel differs from torch.distributions on this build; using torch's")
+    if not ok:
+        return _torch_gumbel(shape, device)
+    return ops.gumbel_from_uniform(torch.rand(tuple(shape), dtype=torch.float32, device=device))
 
 
 def _capacity(num_tokens: int, num_experts: int, capacity_factor: float, min_capacity: int) -> int:
@@ -79,6 +119,7 @@ class _GateFn(torch.autograd.Function):
     def forward(ctx, logits: Tensor, noise: Tensor, C: int):  # type: ignore[override]
         r = ops.gate_top2(logits.contiguous(), noise.contiguous(), C)
         ctx.routing = r
+        ctx.set_materialize_grads(False)  # no zero tensors for the index outputs' "gradients"
         outs = (r.weight, r.l_aux.view(()), r.slot, r.slot_token, r.slot_weight, r.rows, r.exp_counts, r.idx, r.loc)
         ctx.mark_non_differentiable(*outs[2:])
         return outs
@@ -113,6 +154,7 @@ class _RouteDispatchFn(torch.autograd.Function):
         r = ops.gate_top2(logits, noise.contiguous(), C)
         xd = ops.dispatch_fwd(h2d, ve, te, r.slot_token, T, n_vis, mode)
         ctx.routing, ctx.dims = r, (B, T, M, n_vis, mode)
+        ctx.set_materialize_grads(False)  # no zero tensors for the index outputs' "gradients"
         ctx.save_for_backward(h2d, wg32, ve, te)
         ctx.param_dtypes = (wg.dtype, None if vemb is None else vemb.dtype, None if temb is None else temb.dtype)
         outs = (xd, r.weight, r.l_aux.view(()), r.slot, r.slot_token, r.slot_weight, r.rows, r.exp_counts)

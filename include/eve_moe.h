@@ -93,6 +93,12 @@ int eve_gate_top2_fwd(const float* logits, const float* noise, int S, int E, int
                       int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* noise[i] = Gumbel(0,1) variate of the standard-uniform draw uniform[i] in [0,1): the arithmetic of
+ * torch.distributions.Gumbel(0,1).rsample -- low + u*(high-low) with low = tiny, high = 1-eps, then
+ * -log(-log(.)), each step rounded to fp32 -- that the reference's gumbel_rsample performs
+ * (models/sharded_moe.py:70-77, used at :186), in one pass instead of ten elementwise ones. */
+int eve_gumbel_from_uniform(const float* uniform, float* noise, long n, void* stream);
+
 /* Backward of eve_gate_top2_fwd w.r.t. logits (what autograd derives for :172-235):
  * d_weight [S,2] and d_l_aux [1] (device scalar) in, dlogits [S,E] out. */
 int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const int32_t* loc, const float* d_weight,

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import moe_oracle as orc
+from eve_amd import ops
 from tests.helpers import sparse_pairs
 from tests.test_oracle_golden import GATE_CASES
 
@@ -121,3 +122,25 @@ def test_gate_logits_and_wgrad(dtype, mode, B, T, n_vis, M, E):
     dlog = torch.randn(B * T, E, generator=g)
     dwg = ops.gate_wgrad(h2d, ve, te, dlog.to(dev), T, n_vis, code)
     torch.testing.assert_close(dwg.cpu(), dlog.t() @ x, rtol=1e-4, atol=1e-4)
+
+
+def test_fused_gumbel_is_torch_gumbel_bit_for_bit():
+    """gumbel_rsample (one torch.rand + one HIP kernel) vs torch.distributions.Gumbel(0,1).rsample, the
+    call the reference makes (sharded_moe.py:70-77): same values, same generator consumption."""
+    from eve_amd import sharded_moe as sm
+    dev = torch.device("cuda", 0)
+    assert sm._fused_gumbel_matches_torch(dev), "fused kernel differs from torch on this build (fallback would be used)"
+    for shape in [(15168, 32), (7, 3), (1, 1)]:
+        torch.manual_seed(1234)
+        want = sm._torch_gumbel(shape, dev)
+        want_next = torch.rand(5, device=dev)
+        torch.manual_seed(1234)
+        got = sm.gumbel_rsample(shape, dev)
+        got_next = torch.rand(5, device=dev)
+        assert torch.equal(want, got)
+        assert torch.equal(want_next, got_next)  # generator advanced identically
+    # extreme draws: r = 0 and the largest fp32 below 1
+    r = torch.tensor([0.0, 1.0 - 2.0 ** -24], device=dev)
+    tiny, eps = torch.finfo(torch.float32).tiny, torch.finfo(torch.float32).eps
+    u = tiny + r * ((1.0 - eps) - tiny)
+    assert torch.equal(ops.gumbel_from_uniform(r), -torch.log(-torch.log(u)))
