@@ -375,7 +375,7 @@ __device__ __forceinline__ float x_elem(const T* __restrict__ hp, const T* __res
 // (deterministic).  Lane (i = lane & 31, hh = lane >> 5) supplies, for each 16-wide k block, the 8
 // contiguous elements k0 + 8*hh .. +8 of token i (A) and of expert i (B): MFMA step j multiplies
 // k0+j and k0+8+j.
-template <typename T>
+template <typename T, bool EMB>
 __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
                                                                const T* __restrict__ temb,
                                                                const float* __restrict__ wg,
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
   const int kq = ((M / 16 + 3) / 4) * 16;              // K elements per wave (multiple of 16)
   const int k_lo = wave * kq, k_hi = min(M, k_lo + kq);
   const T* hp = h + (size_t)s * M;
-  const T* emb = nullptr;
-  if (mode != EVE_MODE_NONE) emb = token_modality(s, T_, n_vis, mode) ? temb : vemb;
+  const T* emb = nullptr;  // EMB is a template flag so that no load sits behind a per-lane branch
+  if constexpr (EMB) emb = token_modality(s, T_, n_vis, mode) ? temb : vemb;
   const float* wp = wg + (size_t)min(i, E - 1) * M;
   const float wmask = i < E ? 1.f : 0.f;
   f32x16 acc;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
       if constexpr (Vec16<T>::N == 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[u][j] = hv0.get(j);
-        if (emb) {
+        if constexpr (EMB) {
           const Vec16<T> ev = load16<T>(emb + k);
 #pragma unroll
           for (int j = 0; j < 8; ++j) a[u][j] = to_f32<T>(from_f32<T>(a[u][j] + ev.get(j)));
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
         const Vec16<T> hv1 = load16<T>(hp + k + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a[u][j] = hv0.get(j); a[u][4 + j] = hv1.get(j); }
-        if (emb) {
+        if constexpr (EMB) {
           const Vec16<T> e0 = load16<T>(emb + k), e1 = load16<T>(emb + k + 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { a[u][j] += e0.get(j); a[u][4 + j] += e1.get(j); }
@@ -449,59 +449,67 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
 }
 
 // dwg partials: D[32 experts x 32 "virtual" cols] += A[32 experts x 2 tokens] * B[2 tokens x 32 cols].
-// A block owns a chunk of TS tokens; wave w owns columns [256 w, 256 w + 256).  Lane i loads the 8
-// contiguous elements at column 256 w + 8 i of a token with one (bf16) or two (fp32) 16-byte loads
-// and feeds element t to MFMA t, i.e. accumulator t's column j stands for real column 256 w + 8 j + t.
-template <typename T>
-__global__ __launch_bounds__(256) void gate_wgrad_mfma_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
+// Block (x = token chunk of TS tokens, y = group of 256 columns); its 4 waves split the chunk's tokens
+// and are summed through LDS in a fixed order (deterministic).  Lane i loads the 8 contiguous elements
+// at column 256 y + 8 i of a token with one (bf16) or two (fp32) 16-byte loads and feeds element t to
+// MFMA t, i.e. accumulator t's column j stands for real column 256 y + 8 j + t.
+template <typename T, bool EMB>
+__global__ __launch_bounds__(256, 2) void gate_wgrad_mfma_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
                                                               const T* __restrict__ temb,
                                                               const float* __restrict__ dlogits,
                                                               float* __restrict__ part, int S, int T_, int n_vis,
                                                               int mode, int M, int E, int TS) {
+  __shared__ float red[2][8][16][64];  // two waves' accumulators
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int i = lane & 31, hh = lane >> 5;
-  const int col0 = wave * 256 + i * 8;
-  if (wave * 256 >= M) return;  // whole wave has no columns
+  const int col0 = blockIdx.y * 256 + i * 8;
   const bool col_ok = col0 < M;   // M % 8 == 0
-  const int s_begin = blockIdx.x * TS, s_end = min(S, s_begin + TS);
+  const int colc = col_ok ? col0 : 0;  // lanes past the last column load column 0 and store nothing
+  const int ic = min(i, E - 1);
+  const int per_wave = ((TS / 4 + 1) / 2) * 2;  // tokens per wave, even
+  const int s_begin = min(S, blockIdx.x * TS + wave * per_wave);
+  const int s_end = min(min(S, blockIdx.x * TS + TS), s_begin + per_wave);
   f32x16 acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // Loads are unconditional (token index clamped, dead tokens masked through their dlogits factor) so
+  // that all PU token pairs' loads are in flight together; a branch per load would serialise them.
   constexpr int PU = 4;  // token pairs whose loads are issued together
   for (int s2 = s_begin; s2 < s_end; s2 += 2 * PU) {
     float a[PU], b[PU][8];
+    Vec16<T> hv[PU][Vec16<T>::N == 8 ? 1 : 2], ev[PU][Vec16<T>::N == 8 ? 1 : 2];
 #pragma unroll
     for (int u = 0; u < PU; ++u) {
       const int s = s2 + 2 * u + hh;
-      const bool live = s < s_end;
-      const int sc = live ? s : s_begin;
-      a[u] = (live && i < E) ? dlogits[(size_t)sc * E + i] : 0.f;
+      const int sc = min(s, S - 1);
+      a[u] = dlogits[(size_t)sc * E + ic];
+      const T* hp = h + (size_t)sc * M + colc;
+      hv[u][0] = load16<T>(hp);
+      if constexpr (Vec16<T>::N != 8) hv[u][1] = load16<T>(hp + 4);
+      if constexpr (EMB) {
+        const T* emb = (token_modality(sc, T_, n_vis, mode) ? temb : vemb) + colc;
+        ev[u][0] = load16<T>(emb);
+        if constexpr (Vec16<T>::N != 8) ev[u][1] = load16<T>(emb + 4);
+      }
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b[u][j] = 0.f;
-      if (live && col_ok) {
-        const T* hp = h + (size_t)sc * M + col0;
-        const T* emb = nullptr;
-        if (mode != EVE_MODE_NONE) emb = (token_modality(sc, T_, n_vis, mode) ? temb : vemb) + col0;
-        if constexpr (Vec16<T>::N == 8) {
-          const Vec16<T> hv = load16<T>(hp);
+    for (int u = 0; u < PU; ++u) {
+      const int s = s2 + 2 * u + hh;
+      a[u] = (s < s_end && i < E) ? a[u] : 0.f;
+      if constexpr (Vec16<T>::N == 8) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) b[u][j] = hv.get(j);
-          if (emb) {
-            const Vec16<T> ev = load16<T>(emb);
+        for (int j = 0; j < 8; ++j) {
+          b[u][j] = hv[u][0].get(j);
+          if constexpr (EMB) b[u][j] = to_f32<T>(from_f32<T>(b[u][j] + ev[u][0].get(j)));
+        }
+      } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b[u][j] = to_f32<T>(from_f32<T>(b[u][j] + ev.get(j)));
-          }
-        } else {
-          const Vec16<T> h0 = load16<T>(hp), h1 = load16<T>(hp + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { b[u][j] = h0.get(j); b[u][4 + j] = h1.get(j); }
-          if (emb) {
-            const Vec16<T> e0 = load16<T>(emb), e1 = load16<T>(emb + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { b[u][j] += e0.get(j); b[u][4 + j] += e1.get(j); }
-          }
+        for (int j = 0; j < 4; ++j) {
+          b[u][j] = hv[u][0].get(j);
+          b[u][4 + j] = hv[u][1].get(j);
+          if constexpr (EMB) { b[u][j] += ev[u][0].get(j); b[u][4 + j] += ev[u][1].get(j); }
         }
       }
     }
@@ -510,16 +518,59 @@ __global__ __launch_bounds__(256) void gate_wgrad_mfma_kernel(const T* __restric
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
   }
-  if (!col_ok) return;
+  // (w0 + w2) + (w1 + w3)
+  if (wave >= 2) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 2][t][r][lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += red[wave][t][r][lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[0][t][r][lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (wave != 0 || !col_ok) return;
   float* out = part + (size_t)blockIdx.x * E * M;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;  // expert
     if (row >= E) continue;
     float* o = out + (size_t)row * M + col0;
-    *reinterpret_cast<float4*>(o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0][r] + red[0][0][r][lane], acc[1][r] + red[0][1][r][lane],
+                                                acc[2][r] + red[0][2][r][lane], acc[3][r] + red[0][3][r][lane]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4][r] + red[0][4][r][lane], acc[5][r] + red[0][5][r][lane],
+                                                    acc[6][r] + red[0][6][r][lane], acc[7][r] + red[0][7][r][lane]);
   }
+}
+
+// out[i] = sum over parts of part[p][i], in a fixed order: 4 slices of the parts summed by 4 thread
+// groups, then the slices in order.  Block = 64 outputs x 4 slices.
+__global__ __launch_bounds__(256) void sum_partials4_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            int n, int nparts) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  const int per = (nparts + 3) / 4;
+  const int p0 = sl * per, p1 = min(nparts, p0 + per);
+  float acc = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int p = p0; p < p1; ++p) acc += part[(size_t)p * n + i];
+  }
+  red[sl][o] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n) out[i] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
 }
 
 // =================================================================== host launchers
@@ -529,8 +580,12 @@ template <typename T>
 static int launch_logits(const void* h, const void* ve, const void* te, const float* wg, float* logits, int S, int T_,
                          int n_vis, int mode, int M, int E, hipStream_t st) {
   if (E <= 32 && M % 16 == 0) {
-    hipLaunchKernelGGL((gate_logits_mfma_kernel<T>), dim3(ceil_div(S, 32)), dim3(256), 0, st, (const T*)h,
-                       (const T*)ve, (const T*)te, wg, logits, S, T_, n_vis, mode, M, E);
+    if (mode != EVE_MODE_NONE)
+      hipLaunchKernelGGL((gate_logits_mfma_kernel<T, true>), dim3(ceil_div(S, 32)), dim3(256), 0, st, (const T*)h,
+                         (const T*)ve, (const T*)te, wg, logits, S, T_, n_vis, mode, M, E);
+    else
+      hipLaunchKernelGGL((gate_logits_mfma_kernel<T, false>), dim3(ceil_div(S, 32)), dim3(256), 0, st, (const T*)h,
+                         (const T*)ve, (const T*)te, wg, logits, S, T_, n_vis, mode, M, E);
     EVE_CHECK_LAUNCH("gate_logits_mfma_kernel");
     return EVE_OK;
   }
@@ -678,8 +733,8 @@ extern "C" int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const i
 }
 
 static const int kWgradTS = 64;       // VALU kernel
-static const int kWgradMfmaTS = 64;   // fp32-MFMA kernel
-static inline bool wgrad_use_mfma(int M, int E) { return E <= 32 && M % 8 == 0 && M <= 1024; }
+static const int kWgradMfmaTS = 96;   // fp32-MFMA kernel: tokens per block (24 per wave)
+static inline bool wgrad_use_mfma(int M, int E) { return E <= 32 && M % 8 == 0; }
 
 extern "C" size_t eve_gate_wgrad_workspace_bytes(int S, int M, int E) {
   if (S <= 0) return 0;
@@ -700,18 +755,20 @@ extern "C" int eve_gate_wgrad(const void* h, const void* vision_embed, const voi
   if (wgrad_use_mfma(M, E)) {
     const int nbm = ceil_div(S, kWgradMfmaTS);
     EVE_REQUIRE(dtype == EVE_F32 || dtype == EVE_BF16, EVE_ERR_ARG, "eve_gate_wgrad: bad dtype %d", dtype);
-    if (dtype == EVE_F32)
-      hipLaunchKernelGGL((gate_wgrad_mfma_kernel<float>), dim3(nbm), dim3(256), 0, st, (const float*)h,
-                         (const float*)vision_embed, (const float*)text_embed, dlogits, part, S, T, n_vis, mode, M, E,
-                         kWgradMfmaTS);
-    else
-      hipLaunchKernelGGL((gate_wgrad_mfma_kernel<bf16_t>), dim3(nbm), dim3(256), 0, st, (const bf16_t*)h,
-                         (const bf16_t*)vision_embed, (const bf16_t*)text_embed, dlogits, part, S, T, n_vis, mode, M,
-                         E, kWgradMfmaTS);
+    const dim3 grid(nbm, ceil_div(M, 256));
+#define EVE_WG_LAUNCH(TT, EMB)                                                                                    \
+  hipLaunchKernelGGL((gate_wgrad_mfma_kernel<TT, EMB>), grid, dim3(256), 0, st, (const TT*)h, (const TT*)vision_embed, \
+                     (const TT*)text_embed, dlogits, part, S, T, n_vis, mode, M, E, kWgradMfmaTS)
+    if (dtype == EVE_F32) {
+      if (mode != EVE_MODE_NONE) EVE_WG_LAUNCH(float, true); else EVE_WG_LAUNCH(float, false);
+    } else {
+      if (mode != EVE_MODE_NONE) EVE_WG_LAUNCH(bf16_t, true); else EVE_WG_LAUNCH(bf16_t, false);
+    }
+#undef EVE_WG_LAUNCH
     EVE_CHECK_LAUNCH("gate_wgrad_mfma_kernel");
     const int nn = E * M;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(nn, 256)), dim3(256), 0, st, part, dwg, nn, nbm);
-    EVE_CHECK_LAUNCH("sum_partials_kernel");
+    hipLaunchKernelGGL(sum_partials4_kernel, dim3(ceil_div(nn, 64)), dim3(256), 0, st, part, dwg, nn, nbm);
+    EVE_CHECK_LAUNCH("sum_partials4_kernel");
     return EVE_OK;
   }
   const int nb = ceil_div(S, kWgradTS);
