@@ -36,6 +36,7 @@ SIGNATURES = {
     "eve_dispatch_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eve_embed_grad_workspace_bytes": (c_size_t, [_I, _I]),
     "eve_embed_grad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "eve_route_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "eve_combine_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "eve_combine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eve_ffn_fwd": (c_int, [_P] * 9 + [_I] * 7 + [_P]),

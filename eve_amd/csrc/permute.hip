@@ -261,6 +261,119 @@ __global__ __launch_bounds__(256) void embed_grad_final_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------- fused routing backward (E <= 32)
+// dh[s] = dxd[slot1] + dxd[slot2] + dlogits[s,:] @ wg, plus the per-block column sums of the ROUNDED dh
+// by modality (the modality-embedding gradients), in one pass over dh.  A block owns 32 tokens:
+//   1. G[32 tokens x M] = dlogits @ wg on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 FMAs),
+//      each wave every fourth 32-column tile, written to LDS;
+//   2. thread per (token, 16-byte column chunk): G + the two gathered dxd rows -> dh, the rounded values
+//      back into G;
+//   3. thread per column: sums of G over the block's vision / text tokens -> part[block][2][M].
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr int kRbTok = 32;
+constexpr int kRbThreads = 512;
+// blockIdx.y selects a slab of Mb columns (a multiple of 32), so that a block's LDS image stays small
+// enough for several blocks per CU: the kernel is latency-bound and lives on occupancy.
+template <typename T>
+__global__ __launch_bounds__(kRbThreads) void route_bwd_kernel(const T* __restrict__ dxd, const int32_t* __restrict__ slot,
+                                                               const float* __restrict__ dlogits,
+                                                               const float* __restrict__ wg, T* __restrict__ dh,
+                                                               float* __restrict__ part, int S, int T_, int n_vis,
+                                                               int mode, int M, int E, int Mb) {
+  constexpr int N = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* G = reinterpret_cast<float*>(smem);
+  const int ld = Mb + 4;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int s0 = blockIdx.x * kRbTok;
+  const int c0 = blockIdx.y * Mb;            // first column of the slab
+  const int mb = min(Mb, M - c0);            // columns in it (multiple of N)
+  {  // phase 1
+    const int i = lane & 31, hh = lane >> 5;
+    const int tok = min(s0 + i, S - 1);
+    float a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = 2 * j + hh;
+      const float v = dlogits[(size_t)tok * E + min(e, E - 1)];
+      a[j] = e < E ? v : 0.f;
+    }
+    const int ntiles = (mb + 31) / 32;
+    for (int tile = wave; tile < ntiles; tile += kRbThreads / 64) {
+      const int col = tile * 32 + i;
+      const float* wp = wg + c0 + min(col, mb - 1);
+      float b[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) b[j] = wp[(size_t)min(2 * j + hh, E - 1) * M];  // a[j] = 0 masks e >= E
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+      if (col < mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[((r & 3) + 8 * (r >> 2) + 4 * hh) * ld + col] = acc[r];
+      }
+    }
+  }
+  __syncthreads();
+  {  // phase 2: loads are unconditional (clamped) so that several items' gathers are in flight together
+    const int chunks = mb / N;
+    const int items = kRbTok * chunks;
+#pragma unroll 4
+    for (int id = threadIdx.x; id < items; id += kRbThreads) {
+      const int t = id / chunks, c = id - t * chunks;
+      const int s = s0 + t, sc = min(s, S - 1);
+      const int s1 = slot[2 * sc], s2 = slot[2 * sc + 1];
+      const Vec16<T> v1 = load16<T>(dxd + (size_t)max(s1, 0) * M + c0 + c * N);
+      const Vec16<T> v2 = load16<T>(dxd + (size_t)max(s2, 0) * M + c0 + c * N);
+      float* g = G + t * ld + c * N;
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float v = (g[j] + (s1 >= 0 ? v1.get(j) : 0.f)) + (s2 >= 0 ? v2.get(j) : 0.f);
+        o.set(j, v);
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) g[j] = s < S ? o.get(j) : 0.f;
+      if (s < S) store16<T>(dh + (size_t)s * M + c0 + c * N, o);
+    }
+  }
+  if (!part) return;  // block-uniform
+  __syncthreads();
+  for (int col = threadIdx.x; col < mb; col += kRbThreads) {  // phase 3
+    float av = 0.f, at = 0.f;
+    for (int t = 0; t < kRbTok; ++t) {
+      const float v = G[t * ld + col];
+      if (token_modality(min(s0 + t, S - 1), T_, n_vis, mode)) at += v; else av += v;
+    }
+    part[((size_t)blockIdx.x * 2 + 0) * M + c0 + col] = av;
+    part[((size_t)blockIdx.x * 2 + 1) * M + c0 + col] = at;
+  }
+}
+
+// fixed-order sum of the per-block partials: block = 32 columns x 32 slices of the partial rows
+__global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* __restrict__ part, float* __restrict__ dv,
+                                                                  float* __restrict__ dt, int M, int nchunks) {
+  __shared__ float red[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;   // over 2*M columns: [vision M | text M] per chunk row
+  float acc = 0.f;
+  if (col < 2 * M) {
+#pragma unroll 4
+    for (int b = ty; b < nchunks; b += 32) acc += part[(size_t)b * 2 * M + col];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && col < 2 * M) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += red[r][tx];
+    if (col < M) { if (dv) dv[col] = s; }
+    else if (dt) dt[col - M] = s;
+  }
+}
+
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int row_grid(int rows) { return max(1, min(ceil_div(rows, 4), 4096)); }
 
@@ -387,5 +500,55 @@ extern "C" int eve_embed_grad(const void* dh, float* dvision, float* dtext, int 
   hipLaunchKernelGGL(embed_grad_final_kernel, dim3(ceil_div(2 * M, 32)), dim3(256), 0, st, part, dvision, dtext, M,
                      nchunks);
   EVE_CHECK_LAUNCH("embed_grad_final_kernel");
+  return EVE_OK;
+}
+
+// column slab per block: the whole row up to 256 columns, else about half of it (a multiple of 32)
+static inline int route_bwd_slab(int M) { return M <= 256 ? ceil_div(M, 32) * 32 : ceil_div(ceil_div(M, 2), 32) * 32; }
+static inline size_t route_bwd_lds(int M) { return (size_t)kRbTok * (route_bwd_slab(M) + 4) * sizeof(float); }
+
+extern "C" int eve_route_bwd(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh,
+                             float* dvision, float* dtext, int S, int T, int n_vis, int mode, int M, int E, int dtype,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  EVE_REQUIRE(dxd && slot && dlogits && wg && dh, EVE_ERR_ARG, "eve_route_bwd: null pointer");
+  EVE_REQUIRE(S > 0 && E > 0, EVE_ERR_ARG, "eve_route_bwd: bad shape");
+  if (int rc = check_rows("eve_route_bwd", M, dtype)) return rc;
+  const bool want_embed = mode != EVE_MODE_NONE && (dvision || dtext);
+  if (want_embed) {
+    EVE_REQUIRE(T > 0 && S % T == 0, EVE_ERR_ARG, "eve_route_bwd: S=%d not a multiple of T=%d", S, T);
+    const size_t need = eve_embed_grad_workspace_bytes(S, M);
+    EVE_REQUIRE(workspace && workspace_bytes >= need, EVE_ERR_WORKSPACE, "eve_route_bwd: workspace %zu < %zu",
+                workspace_bytes, need);
+  }
+  if (E > 32 || route_bwd_lds(M) > 160 * 1024) {  // shapes the fused kernel does not cover: the two-pass path
+    if (int rc = eve_dispatch_bwd(dxd, slot, dlogits, wg, dh, S, M, E, dtype, stream)) return rc;
+    if (want_embed) return eve_embed_grad(dh, dvision, dtext, S, T, n_vis, mode, M, dtype, workspace, workspace_bytes, stream);
+    return EVE_OK;
+  }
+  static_assert(kRbTok == kEmbedTS, "eve_embed_grad_workspace_bytes sizes the partials of both paths");
+  hipStream_t st = S_(stream);
+  const int nblk = ceil_div(S, kRbTok);
+  const size_t lds = route_bwd_lds(M);
+  const int Mb = route_bwd_slab(M);
+  float* part = want_embed ? static_cast<float*>(workspace) : nullptr;
+#define EVE_RB_LAUNCH(TT)                                                                                          \
+  do {                                                                                                             \
+    auto kern = route_bwd_kernel<TT>;                                                                              \
+    static size_t attr_bytes = 0;                                                                                  \
+    if (lds > 64 * 1024 && lds > attr_bytes) {                                                                     \
+      EVE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds) == hipSuccess, EVE_ERR_LAUNCH, "eve_route_bwd: cannot reserve %zu bytes of LDS", lds); \
+      attr_bytes = lds;                                                                                            \
+    }                                                                                                              \
+    hipLaunchKernelGGL(kern, dim3(nblk, ceil_div(M, Mb)), dim3(kRbThreads), lds, st, (const TT*)dxd, slot, dlogits,  \
+                       wg, (TT*)dh, part, S, T, n_vis, mode, M, E, Mb);                                            \
+  } while (0)
+  if (dtype == EVE_F32) EVE_RB_LAUNCH(float); else EVE_RB_LAUNCH(bf16_t);
+#undef EVE_RB_LAUNCH
+  EVE_CHECK_LAUNCH("route_bwd_kernel");
+  if (want_embed) {
+    hipLaunchKernelGGL(embed_grad_final32_kernel, dim3(ceil_div(2 * M, 32)), dim3(1024), 0, st, part, dvision, dtext, M, nblk);
+    EVE_CHECK_LAUNCH("embed_grad_final32_kernel");
+  }
   return EVE_OK;
 }

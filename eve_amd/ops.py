@@ -182,6 +182,25 @@ def dispatch_bwd(dxd: torch.Tensor, slot: torch.Tensor, dlogits, wg, S: int) -> 
     return dh
 
 
+def route_bwd(dxd, slot, dlogits, wg, S: int, T: int, n_vis: int, mode: int, want_v: bool, want_t: bool):
+    """dispatch_bwd + embed_grad in one pass: -> (dh [S,M], dvision|None, dtext|None)."""
+    _chk(dxd, "dxd"), _chk(slot, "slot", torch.int32), _chk(dlogits, "dlogits", torch.float32)
+    _chk(wg, "wg", torch.float32)
+    M = dxd.shape[-1]
+    E = wg.shape[0]
+    dev = dxd.device
+    dh = torch.empty(S, M, dtype=dxd.dtype, device=dev)
+    want_v = want_v and mode != _lib.MODE_NONE
+    want_t = want_t and mode != _lib.MODE_NONE
+    dv = torch.empty(M, dtype=torch.float32, device=dev) if want_v else None
+    dt = torch.empty(M, dtype=torch.float32, device=dev) if want_t else None
+    nbytes = _lib.load().eve_embed_grad_workspace_bytes(S, M) if (want_v or want_t) else 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+    PROFILE.call("eve_route_bwd", _p(dxd), _p(slot), _p(dlogits), _p(wg), _p(dh), _p(dv), _p(dt), S, T, n_vis, mode, M, E,
+                 _dt(dxd), _p(ws), nbytes, _stream())
+    return dh, dv, dt
+
+
 def embed_grad(dh: torch.Tensor, T: int, n_vis: int, mode: int, want_v=True, want_t=True):
     _chk(dh, "dh")
     S, M = dh.shape

@@ -173,16 +173,13 @@ class _RouteDispatchFn(torch.autograd.Function):
         dlogits = ops.gate_top2_bwd(r, d_weight.contiguous(), dl)
         if dxd is None:
             dxd = torch.zeros(r.E * r.C, M, dtype=h2d.dtype, device=h2d.device)
-        dh = ops.dispatch_bwd(dxd.contiguous(), r.slot, dlogits, wg32, S)
         wg_dt, v_dt, t_dt = ctx.param_dtypes
+        want_v = mode in (_lib.MODE_VL, _lib.MODE_VISION) and ctx.needs_input_grad[2]
+        want_t = mode in (_lib.MODE_VL, _lib.MODE_TEXT) and ctx.needs_input_grad[3]
+        dh, dv, dt = ops.route_bwd(dxd.contiguous(), r.slot, dlogits, wg32, S, T, n_vis, mode, want_v, want_t)
         dwg = ops.gate_wgrad(h2d, ve, te, dlogits, T, n_vis, mode).to(wg_dt) if ctx.needs_input_grad[1] else None
-        dv = dt = None
-        if mode != _lib.MODE_NONE and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
-            want_v = ctx.needs_input_grad[2] and mode in (_lib.MODE_VL, _lib.MODE_VISION)
-            want_t = ctx.needs_input_grad[3] and mode in (_lib.MODE_VL, _lib.MODE_TEXT)
-            dv, dt = ops.embed_grad(dh, T, n_vis, mode, want_v, want_t)
-            dv = None if dv is None else dv.to(v_dt)
-            dt = None if dt is None else dt.to(t_dt)
+        dv = None if dv is None else dv.to(v_dt)
+        dt = None if dt is None else dt.to(t_dt)
         return dh.view(B, T, M), dwg, dv, dt, None, None, None, None, None
 
 

@@ -131,6 +131,14 @@ size_t eve_embed_grad_workspace_bytes(int S, int M);
 int eve_embed_grad(const void* dh, float* dvision, float* dtext, int S, int T, int n_vis, int mode, int M, int dtype,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* eve_dispatch_bwd and eve_embed_grad in one pass over dh (the backward of the routing front end,
+ * models/sharded_moe.py:350-367 as autograd differentiates it): dh as eve_dispatch_bwd (dlogits and wg
+ * required), and -- when mode != EVE_MODE_NONE -- dvision / dtext [M] fp32 as eve_embed_grad (either may
+ * be NULL).  workspace: eve_embed_grad_workspace_bytes(S, M) (unused when no embedding gradient is wanted). */
+int eve_route_bwd(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh,
+                  float* dvision, float* dtext, int S, int T, int n_vis, int mode, int M, int E, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[s,:] = weight[s,0]*y[slot[s,0],:] + weight[s,1]*y[slot[s,1],:]  (fp32 accumulate).
  * Replaces einsum("sec,ecm->sm", combine_weights, expert_output), models/sharded_moe.py:377. */
 int eve_combine_fwd(const void* y, const int32_t* slot, const float* weight, void* out, int S, int M, int dtype,

@@ -133,3 +133,57 @@ def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
         scale = float(ref.abs().max().clamp(min=1e-6))
         err = float((got.cpu().double() - ref).abs().max()) / scale
         assert err < (2e-2 if dtype == torch.bfloat16 else 2e-5), (name, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,n_vis,M,E,mode", [(3, 37, 5, 64, 8, "vl"), (4, 237, 197, 768, 32, "vl"),
+                                                  (2, 33, 0, 256, 32, "text"), (2, 50, 7, 128, 5, "vision"),
+                                                  (1, 31, 0, 72, 3, "none")])
+def test_route_bwd_matches_two_pass(dtype, B, T, n_vis, M, E, mode):
+    """eve_route_bwd (fused, fp32-MFMA gate part) vs eve_dispatch_bwd + eve_embed_grad, and vs fp64 torch."""
+    from eve_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    S, C = B * T, max(4, (2 * B * T) // E)
+    slot = torch.full((S, 2), -1, dtype=torch.int32)
+    perm = torch.randperm(E * C, generator=g)[: 2 * S].to(torch.int32)
+    n_fill = min(2 * S, E * C)
+    flat = slot.view(-1)
+    pos = torch.randperm(2 * S, generator=g)[: int(n_fill * 0.9)]
+    flat[pos] = perm[: pos.numel()]
+    dxd = torch.randn(E * C, M, generator=g).to(dtype)
+    dlogits = torch.randn(S, E, generator=g) * 0.1
+    wg = torch.randn(E, M, generator=g) * 0.05
+    mcode = ops.MODES[mode]
+    args = [t.to(dev) for t in (dxd, slot, dlogits, wg)]
+    dh, dv, dt = ops.route_bwd(*args, S, T, n_vis, mcode, True, True)
+    dh_ref = ops.dispatch_bwd(*args, S)
+    torch.cuda.synchronize()
+    # fp64 reference of dh
+    want = dlogits.double() @ wg.double()
+    for k in range(2):
+        sl = slot[:, k].long()
+        want += torch.where((sl >= 0)[:, None], dxd.double()[sl.clamp(min=0)], torch.zeros(1, dtype=torch.float64))
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(dh.cpu().double(), want, **tol)
+    torch.testing.assert_close(dh.cpu().double(), dh_ref.cpu().double(), **tol)
+    if mode == "none":
+        assert dv is None and dt is None
+        return
+    # embedding gradients = column sums of the ROUNDED dh by modality (what eve_embed_grad computes from dh)
+    dv_ref, dt_ref = ops.embed_grad(dh, T, n_vis, mcode, True, True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dv, dv_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dt, dt_ref, rtol=1e-5, atol=1e-5)
+    is_text = torch.tensor([orc_is_text(s, T, n_vis, mode) for s in range(S)])
+    d64 = dh.cpu().double()
+    torch.testing.assert_close(dv.cpu().double(), d64[~is_text].sum(0), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dt.cpu().double(), d64[is_text].sum(0), rtol=1e-4, atol=1e-4)
+
+
+def orc_is_text(s, T, n_vis, mode):
+    if mode == "vision":
+        return False
+    if mode == "text":
+        return True
+    return (s % T) >= n_vis
