@@ -77,9 +77,9 @@ struct MfmaPair {
 // stamp k of K tile t goes to lane 5t+k of one VGPR (no memory traffic inside the loop); tiles 0..11
 #define EVE_STAMP(k)                                                                                     \
   do {                                                                                                   \
-    if (t < 12) {                                                                                        \
+    if (t < 10) {                                                                                        \
       const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime();                                        \
-      stamp_v = lane == t * 5 + (k) ? c_ : stamp_v;                                                      \
+      stamp_v = lane == t * 6 + (k) ? c_ : stamp_v;                                                      \
     }                                                                                                    \
   } while (0)
 #else
@@ -182,8 +182,8 @@ template <int PER> __device__ __forceinline__ void wait_tiles_in_flight(int tile
 // Epilogue of one block tile.  Per wave, one 32-row slab (MFMA row tile i) at a time through a private
 // fp32 LDS image, so that global stores are 16 B per lane along rows.  Only the wave itself touches
 // its image; waves are laid out (wave >> 2) x (wave & 3) over 128 x 64 outputs each.
-template <int EPI, int ACT>
-__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WTM][WTN], char* smem, const MfmaDesc& d, int z, int e_out,
+template <int EPI, int ACT, int WR = WTM>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WR][WTN], char* smem, const MfmaDesc& d, int z, int e_out,
                                               int m0, int n0, int mext, int wave, int lane) {
   const int wm = wave >> 2, wn = wave & 3;
   float* ep = reinterpret_cast<float*>(smem) + wave * 32 * EPI_LD;
@@ -208,15 +208,15 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WTM][WTN], cha
     if constexpr (EPI == MEPI_DACT) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int m = min(m0 + wm * 128 + i * 32 + it * 8 + irow, mext - 1);
+        const int m = min(m0 + wm * (WR * 32) + i * 32 + it * 8 + irow, mext - 1);
         dst[it] = *reinterpret_cast<const uint4*>(Zg + (size_t)m * d.ldc + ncol);
       }
     }
   };
   load_z(0, zbuf[0]);
 #pragma unroll
-  for (int i = 0; i < WTM; ++i) {
-    if (i + 1 < WTM) load_z(i + 1, zbuf[(i + 1) & 1]);
+  for (int i = 0; i < WR; ++i) {
+    if (i + 1 < WR) load_z(i + 1, zbuf[(i + 1) & 1]);
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int j = 0; j < WTN; ++j)
@@ -230,7 +230,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WTM][WTN], cha
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + irow;
-      const int m = m0 + wm * 128 + i * 32 + row;
+      const int m = m0 + wm * (WR * 32) + i * 32 + row;
       const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8);
       const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8 + 4);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -490,7 +490,7 @@ __device__ __forceinline__ uint32_t sub_dma_offset0(int ld, int w4, int lane) {
 }
 template <bool COL> __device__ __forceinline__ uint32_t sub_dma_stride(int ld) { return (uint32_t)(COL ? 8 : 32) * (uint32_t)ld * 2u; }
 
-template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI>
+template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
 __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // Two independent problems of the same kind may share a launch (the two weight-gradient GEMMs of a
@@ -499,10 +499,14 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   const bool second = blockIdx.x >= (unsigned)pr.n0;
   const MfmaDesc& d = pr.d[second ? 1 : 0];
   const unsigned bid = second ? blockIdx.x - (unsigned)pr.n0 : blockIdx.x;
-  constexpr int BM = 256, KI = BKI / 16, NSLOT = 5;
-  constexpr int kSub = 256 * BKI * 2;       // bytes of one sub-tile
-  constexpr int NP = kSub / 1024 / 4;       // DMA instructions per wave per sub-tile
-  static_assert(NP % KI == 0, "DMA pieces interleave evenly with the k16 steps");
+  // WR = MFMA row tiles per wave: 4 -> 256-row block tiles, 3 -> 192-row tiles (row-major A only),
+  // which pack N = 768 problems on 256 CUs without a half-empty last wave of tiles.
+  constexpr int BM = 64 * WR, KI = BKI / 16, NSLOT = 5;
+  static_assert(WR == 4 || (WR == 3 && !A_COL && !WGRAD), "192-row tiles: row-major A only");
+  constexpr int kSub = 256 * BKI * 2;       // bytes of one ring slot (a 256 x BKI sub-tile)
+  constexpr int NPB = kSub / 1024 / 4;      // DMA instructions per wave per B sub-tile
+  constexpr int NPA = BM * BKI * 2 / 1024 / 4;  // ... per A sub-tile
+  constexpr int NP = NPB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -529,9 +533,9 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
   if (m0 >= mext) return;
 
-  f32x16 acc[WTM][WTN];
+  f32x16 acc[WR][WTN];
 #pragma unroll
-  for (int i = 0; i < WTM; ++i)
+  for (int i = 0; i < WR; ++i)
 #pragma unroll
     for (int j = 0; j < WTN; ++j)
 #pragma unroll
@@ -548,6 +552,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   // waves 0-3 only ever fetch B tiles, waves 4-7 only A tiles
   const uint32_t voff0 = h == 0 ? sub_dma_offset0<B_COL, BKI>(d.ldb, w4, lane) : sub_dma_offset0<A_COL, BKI>(d.lda, w4, lane);
   const uint32_t vstride = h == 0 ? sub_dma_stride<B_COL>(d.ldb) : sub_dma_stride<A_COL>(d.lda);
+  const int np = h == 0 ? NPB : NPA;  // pieces per wave of my operand's sub-tile
 
   const int nseg = WGRAD ? d.G / d.E_local : 1;
   for (int seg = 0; seg < nseg; ++seg) {
@@ -578,9 +583,9 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
                                                voff0 + (origin + (uint32_t)i * vstride), 0, 0, 0);
     };
 
-    bf16x8 fa[KI][WTM], fb[KI][WTN];
+    bf16x8 fa[KI][WR], fb[KI][WTN];
     // L phase: fragment reads of tile t, interleaved with the DMA pieces of the tile fetched now
-    auto load_phase = [&](int sl_a, bool fetch, int tf) {
+    auto load_phase = [&](int sl_a, bool fetch, int tf, int t) {
       const int sl_b = sl_a + 1 >= NSLOT ? sl_a + 1 - NSLOT : sl_a + 1;
       // B(t+1) goes 2 slots past B(t); A(t+2) goes 4 slots past A(t)
       const int sl_f = h == 0 ? (sl_b + 2 >= NSLOT ? sl_b + 2 - NSLOT : sl_b + 2) : (sl_a + 4 >= NSLOT ? sl_a + 4 - NSLOT : sl_a + 4);
@@ -588,12 +593,26 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
       const char* sb = smem + sl_b * kSub;
       char* slot = smem + sl_f * kSub;
       const uint32_t origin = my_origin(tf);
+      // With plain (non-transposed) fragment reads the fetch is interleaved with them: the DMA issue is
+      // paced by the CU's texture path and the reads by the LDS, so side by side the phase is shorter.
+#ifdef EVE_PP_STAMP
+      constexpr bool kInterleave = false;
+#else
+      constexpr bool kInterleave = !A_COL && !B_COL && !BIAS_GRAD;
+#endif
 #pragma unroll
       for (int ks = 0; ks < KI; ++ks) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) fb[ks][j] = frag_load<B_COL, BN>(sb, wn * 64 + j * 32, ks, lane);
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) fa[ks][i] = frag_load<A_COL, BM>(sa, wm * 128 + i * 32, ks, lane);
+        for (int i = 0; i < WR; ++i) fa[ks][i] = frag_load<A_COL, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
+        if constexpr (kInterleave) {
+          if (fetch) {
+#pragma unroll
+            for (int i = ks * (NP / KI); i < (ks + 1) * (NP / KI); ++i)
+              if (i < np) dma_piece(slot, origin, i);
+          }
+        }
       }
       if constexpr (BIAS_GRAD) {
         if (do_bias_grad) {  // column sums of the k-major A tile, read back from LDS
@@ -609,9 +628,11 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
       }
       // The fetch is issued after the reads: the compiler puts a vmcnt(0) in front of a transposed LDS
       // read that follows an LDS-DMA in program order, which would make the wave wait for its own fetch.
-      if (fetch) {
+      EVE_STAMP(5);  // diagnostic build: fragment reads complete (the stamp drains lgkmcnt), fetch not yet issued
+      if (!kInterleave && fetch) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) dma_piece(slot, origin, i);
+        for (int i = 0; i < NP; ++i)
+          if (i < np) dma_piece(slot, origin, i);
       }
     };
 
@@ -620,12 +641,14 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
       char* s0 = my_slot(0);
       const uint32_t o0 = my_origin(0);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) dma_piece(s0, o0, i);
+      for (int i = 0; i < NP; ++i)
+        if (i < np) dma_piece(s0, o0, i);
       if (h == 1 && nk > 1) {
         char* s1 = my_slot(1);
         const uint32_t o1 = my_origin(1);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) dma_piece(s1, o1, i);
+        for (int i = 0; i < NP; ++i)
+          if (i < np) dma_piece(s1, o1, i);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -635,7 +658,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
     for (int t = 0; t < nk; ++t) {
       const int tf = t + 1 + h;  // waves 0-3 fetch B(t+1), waves 4-7 fetch A(t+2)
       EVE_STAMP(0);
-      load_phase(sl_a, tf < nk, tf);
+      load_phase(sl_a, tf < nk, tf, t);
       sl_a = sl_a + 2 >= NSLOT ? sl_a + 2 - NSLOT : sl_a + 2;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       EVE_STAMP(1);
@@ -646,7 +669,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #pragma unroll
       for (int ks = 0; ks < KI; ++ks)
 #pragma unroll
-        for (int i = 0; i < WTM; ++i)
+        for (int i = 0; i < WR; ++i)
 #pragma unroll
           for (int j = 0; j < WTN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
@@ -665,7 +688,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #ifdef EVE_PP_STAMP
   { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 60 ? c_ : stamp_v; }
 #endif
-  tile_epilogue<EPI, ACT>(acc, smem, d, z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+  tile_epilogue<EPI, ACT, WR>(acc, smem, d, z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
   if constexpr (BIAS_GRAD) {
     if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, z, m0);  // block-uniform
   }
@@ -717,13 +740,13 @@ static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
   return EVE_OK;
 }
 
-template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI>
+template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI, int WR = 4>
 static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc* d2 = nullptr) {
   constexpr int kEpi = 8 * 32 * EPI_LD * 4;
   constexpr int kLds = 5 * 256 * BKI * 2 > kEpi ? 5 * 256 * BKI * 2 : kEpi;
   auto blocks = [](const MfmaDesc& q) {
     const int ngroups = WGRAD ? q.E_local : q.G;
-    return 8 * ceil_div(ngroups, 8) * (q.N / BN) * ceil_div(q.Mext, 256);
+    return 8 * ceil_div(ngroups, 8) * (q.N / BN) * ceil_div(q.Mext, 64 * WR);
   };
   MfmaPair pr;
   pr.d[0] = d;
@@ -732,7 +755,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   dim3 grid(pr.n0 + (d2 ? blocks(*d2) : 0));
 #define EVE_PP_LAUNCH(A)                                                                                     \
   do {                                                                                                       \
-    auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI>;                                \
+    auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                                \
     static bool attr_done = false;                                                                           \
     if (!attr_done) {                                                                                        \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -768,14 +791,35 @@ static bool use_pingpong() {
   return !(v && v[0] == 'l');
 }
 
-// Tile choice: 256 x 256 tiles (8 waves, ping-pong schedule) unless the row extent is small enough
-// that a 256-row tile would be mostly padding (then 128 x 256 tiles, 4 waves).
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+// Tile choice.  One workgroup fills a CU, so a launch costs about ceil(tiles / CUs) * rows-per-tile:
+// 256 x 256 tiles (8 waves, ping-pong schedule) by default; 192 x 256 tiles when they need clearly
+// fewer row-steps (e.g. 3 column tiles x 948 rows x 32 experts: 480 tiles of 192 rows fill two waves of
+// 256 CUs, where 384 tiles of 256 rows leave the second wave half empty); 128 x 256 tiles (4 waves) when
+// the row extent is small enough that a larger tile would be mostly padding.
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
 static int launch(const MfmaDesc& d, int act, hipStream_t st) {
   const bool small = !WGRAD && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024));
   if (small) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
-  if (use_pingpong()) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, (A_COL && B_COL) ? 32 : 64>(d, act, st);
-  return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
+  if (!use_pingpong()) return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
+  if constexpr (!A_COL && !WGRAD) {
+    const char* v = getenv("EVE_FFN_TILE_ROWS");  // debug knob: force 192 or 256
+    const long cus = cu_count(), per = (long)d.G * (d.N / BN);
+    const long cost256 = ceil_div(per * ceil_div(d.Mext, 256), cus) * 256;
+    const long cost192 = ceil_div(per * ceil_div(d.Mext, 192), cus) * 192;
+    const bool use192 = v ? atoi(v) == 192 : cost192 * 10 < cost256 * 9;
+    if (use192) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, 64, 3>(d, act, st);
+  }
+  return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, (A_COL && B_COL) ? 32 : 64>(d, act, st);
 }
 
 int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* z, void* a,

@@ -10,7 +10,7 @@
 
 using namespace eve;
 
-template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BG, int BKI>
+template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BG, int BKI, int WR = 4>
 static void run(const char* name, int G, int R, int N, int K, bool bcol, int same_tile = 0) {
   const size_t na = (size_t)G * R * K, nb = (size_t)G * N * K, nc = (size_t)G * R * N;
   std::vector<unsigned short> ha(na), hb(nb);
@@ -30,11 +30,11 @@ static void run(const char* name, int G, int R, int N, int K, bool bcol, int sam
   d.B = B; d.b_g = (long)N * K; d.ldb = bcol ? N : K;
   d.C = C; d.C2 = C; d.c_g = (long)R * N; d.ldc = N; d.bias = bias; d.Zin = Z; d.N = N; d.K = K;
   d.dbg = nullptr; d.same_tile = same_tile;
-  for (int i = 0; i < 20; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI>(d, EVE_ACT_QUICK_GELU, 0);
+  for (int i = 0; i < 20; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, EVE_ACT_QUICK_GELU, 0);
   hipDeviceSynchronize();
   hipMemset(dbg, 0, 2 * 8 * 64 * 8);
   d.dbg = dbg;
-  launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI>(d, EVE_ACT_QUICK_GELU, 0);
+  launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, EVE_ACT_QUICK_GELU, 0);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(2 * 8 * 64);
   hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
@@ -48,11 +48,11 @@ static void run(const char* name, int G, int R, int N, int K, bool bcol, int sam
         auto df = [](unsigned long long x, unsigned long long y) { return (long long)(int)((unsigned)x - (unsigned)y); };
         printf("   kernel start -> first L phase %lld ; epilogue (incl. store drain) %lld ; whole wave %lld\n", df(s[0], s[62]), df(s[61], s[60]), df(s[61], s[62]));
       }
-      for (int t = 3; t < 6; ++t) {
-        const unsigned long long* s = &h[(b * 8 + w) * 64 + t * 5];
-        const unsigned long long* n = s + 5;
+      for (int t = 4; t < 6; ++t) {
+        const unsigned long long* s = &h[(b * 8 + w) * 64 + t * 6];
+        const unsigned long long* n = s + 6;
         auto df = [](unsigned long long x, unsigned long long y) { return (long long)(int)((unsigned)x - (unsigned)y); };
-        printf("   t=%2d  %6lld %6lld %6lld %6lld %6lld   [%lld]\n", t, df(s[1], s[0]), df(s[2], s[1]), df(s[3], s[2]),
+        printf("   t=%2d  reads %5lld dma %5lld | %6lld %6lld %6lld %6lld   [%lld]\n", t, df(s[5], s[0]), df(s[1], s[5]), df(s[2], s[1]), df(s[3], s[2]),
                df(s[4], s[3]), df(n[0], s[4]), df(s[0], base0[0]));
       }
     }
@@ -60,10 +60,8 @@ static void run(const char* name, int G, int R, int N, int K, bool bcol, int sam
 }
 
 int main() {
-  run<false, false, MEPI_BIAS, false, false, 64>("fwd2  (row,row) N=768 K=3072", 32, 948, 768, 3072, false);
-  run<false, false, MEPI_BIAS, false, false, 64>("fwd2  SAME TILE (all L2 hits)", 32, 948, 768, 3072, false, 1);
-  run<false, true, MEPI_STORE, false, false, 64>("dgrad1 (row,col) N=768 K=3072", 32, 948, 768, 3072, true);
-  run<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1  (row,row) N=3072 K=768", 32, 948, 3072, 768, false);
-  run<false, true, MEPI_DACT, false, false, 64>("dgrad2 (row,col) N=3072 K=768", 32, 948, 3072, 768, true);
+  run<false, false, MEPI_BIAS, false, false, 64>("fwd2  (row,row) N=768 K=3072, 256-row tiles", 32, 948, 768, 3072, false);
+  run<false, false, MEPI_BIAS, false, false, 64, 3>("fwd2  (row,row) N=768 K=3072, 192-row tiles", 32, 948, 768, 3072, false);
+  run<false, true, MEPI_STORE, false, false, 64, 3>("dgrad1 (row,col) N=768 K=3072, 192-row tiles", 32, 948, 768, 3072, true);
   return 0;
 }
