@@ -158,6 +158,85 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
   }
 }
 
+// Pass 1 for E <= 32: 256 threads per 64-token block.  Part A works with one lane per (token, expert)
+// -- a wave handles two tokens at a time, its 32-lane halves reduce max / sum / arg-max with butterflies
+// -- so that logits, noise and gates move as coalesced 128-byte rows; part B is the ballot ranking of
+// the kernel above with the experts split over the four waves.  Same outputs, same workspace layout.
+__device__ __forceinline__ void argmax_step(float& v, int& i, int off) {
+  const float ov = __shfl_xor(v, off, 64);
+  const int oi = __shfl_xor(i, off, 64);
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(256) void gate_select32_kernel(
+    const float* __restrict__ logits, const float* __restrict__ noise, int S, int E, float* __restrict__ gates,
+    int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank, float* __restrict__ gsum,
+    int32_t* __restrict__ slot_token, int num_slots) {
+  __shared__ int ci1[kGateBlock], ci2[kGateBlock];
+  __shared__ float gpart[4][32];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_slots; i += gridDim.x * blockDim.x) slot_token[i] = -1;
+
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int e = lane & 31, tk = lane >> 5;
+  const int ec = min(e, E - 1);
+  float gacc = 0.f;
+#pragma unroll 4
+  for (int it = 0; it < kGateBlock / 8; ++it) {
+    const int t = wave * (kGateBlock / 4) + 2 * it + tk;  // token inside the block
+    const int s = blockIdx.x * kGateBlock + t;
+    const bool live = s < S, valid = live && e < E;
+    const size_t o = (size_t)(live ? s : 0) * E + ec;
+    const float x = logits[o], nz = noise[o];
+    float mx = valid ? x : -INFINITY;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float ex = valid ? expf(x - mx) : 0.f;
+    float sum = ex;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float g = ex / sum;
+    if (valid) gates[o] = g;
+    gacc += valid ? g : 0.f;
+    float v1 = valid ? g : -INFINITY;
+    int i1 = e;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) argmax_step(v1, i1, off);
+    float v2 = (valid && e != i1) ? x + nz : -INFINITY;
+    int i2 = e;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) argmax_step(v2, i2, off);
+    if (e == 0) {
+      ci1[t] = live ? i1 : -1;
+      ci2[t] = live ? i2 : -1;  // E == 1: every candidate is -inf and the tie goes to expert 0, as torch.argmax
+    }
+  }
+  gacc += __shfl_xor(gacc, 32, 64);
+  if (lane < 32) gpart[wave][lane] = gacc;
+  __syncthreads();
+  if (threadIdx.x < E)
+    gsum[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+        ((gpart[0][threadIdx.x] + gpart[1][threadIdx.x]) + gpart[2][threadIdx.x]) + gpart[3][threadIdx.x];
+
+  // part B: lane = token
+  const int s = blockIdx.x * kGateBlock + lane;
+  const int i1 = ci1[lane], i2 = ci2[lane];
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int x = wave; x < E; x += 4) {
+    const unsigned long long m1 = __ballot(i1 == x);
+    const unsigned long long m2 = __ballot(i2 == x);
+    if (i1 == x) rank[2 * s] = __popcll(m1 & lt);
+    if (i2 == x) rank[2 * s + 1] = __popcll(m2 & lt);
+    if (lane == 0) {
+      hist[(size_t)x * gridDim.x + blockIdx.x] = __popcll(m1);
+      hist[(size_t)(E + x) * gridDim.x + blockIdx.x] = __popcll(m2);
+    }
+  }
+  if (wave == 0 && s < S) {
+    idx[2 * s] = i1;
+    idx[2 * s + 1] = i2;
+  }
+}
+
 // Pass 2 (scan): single block.  Exclusive prefix of the block histograms over blocks for each
 // (choice, expert); totals; exp_counts; rows; l_aux.
 __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restrict__ hist, int32_t* __restrict__ boff,
@@ -172,30 +251,45 @@ __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restri
   // blocks 4l .. 4l+3 (one 16-byte load), the 64 lane totals are scanned across the wave, and the
   // lane writes its four exclusive prefixes with one 16-byte store.  nblk is padded to a multiple of 4
   // in the workspace layout, so the vector accesses stay inside the row.
-  const int nb4 = (nblk + 3) & ~3;
-  for (int pair = wave; pair < 2 * E; pair += nw) {
-    const int32_t* hrow = hist + (size_t)pair * nblk;
-    int32_t* brow = boff + (size_t)pair * nblk;
-    int carry = 0;
+  constexpr int R = 4;  // rows whose loads are in flight together
+  for (int pair0 = wave; pair0 < 2 * E; pair0 += R * nw) {
+    int carry[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) carry[r] = 0;
     for (int c0 = 0; c0 < nblk; c0 += 256) {
       const int b = c0 + 4 * lane;
-      int v[4] = {0, 0, 0, 0};
+      int v[R][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (b + j < nblk) v[j] = hrow[b + j];
-      const int run = v[0] + v[1] + v[2] + v[3];
-      const int inc = wave_incl_scan(run);
-      int pre = carry + inc - run;
+      for (int r = 0; r < R; ++r) {
+        const int pair = min(pair0 + r * nw, 2 * E - 1);
+        const int32_t* hrow = hist + (size_t)pair * nblk;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (b + j < nblk) brow[b + j] = pre;
-        pre += v[j];
+        for (int j = 0; j < 4; ++j) v[r][j] = hrow[min(b + j, nblk - 1)];
       }
-      carry += __shfl(inc, 63, 64);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int pair = pair0 + r * nw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (b + j >= nblk) v[r][j] = 0;
+        const int run = v[r][0] + v[r][1] + v[r][2] + v[r][3];
+        const int inc = wave_incl_scan(run);
+        int pre = carry[r] + inc - run;
+        if (pair < 2 * E) {
+          int32_t* brow = boff + (size_t)pair * nblk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (b + j < nblk) brow[b + j] = pre;
+            pre += v[r][j];
+          }
+        }
+        carry[r] += __shfl(inc, 63, 64);
+      }
     }
-    if (lane == 0) stot[pair] = carry;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (lane == 0 && pair0 + r * nw < 2 * E) stot[pair0 + r * nw] = carry[r];
   }
-  (void)nb4;
   for (int e = wave; e < E; e += nw) {  // fixed lane-strided order, then butterfly: deterministic
     float g = 0.f;
     for (int b = lane; b < nblk; b += 64) g += gsum[(size_t)e * nblk + b];
@@ -291,6 +385,53 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     if (e == i1) dg += dg1;
     if (e == i2) dg += dg2;
     dlogits[(size_t)s * E + e] = g[e] * (dg - dot);
+  }
+}
+
+// Backward for E <= 32: one lane per (token, expert), two tokens per wave; rows move as coalesced
+// 128-byte loads / stores and the softmax-Jacobian dot product is a butterfly over the 32-lane half.
+__global__ __launch_bounds__(256) void gate_bwd32_kernel(const float* __restrict__ gates, const int32_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ loc,
+                                                         const float* __restrict__ d_weight,
+                                                         const float* __restrict__ d_l_aux,
+                                                         const int64_t* __restrict__ exp_counts, int S, int E, int C,
+                                                         float* __restrict__ dlogits) {
+  const int lane = lane_id();
+  const int e = lane & 31, tk = lane >> 5;
+  const int ec = min(e, E - 1);
+  const float dl = d_l_aux ? d_l_aux[0] : 0.f;
+  const float aux_scale = dl * (float)E / ((float)S * (float)S);
+  const float aux = aux_scale * (float)exp_counts[ec];
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  for (int s0 = 2 * wid; s0 < S; s0 += 2 * nw) {
+    const int s = s0 + tk;
+    const bool live = s < S, valid = live && e < E;
+    const int sc = live ? s : S - 1;
+    const float g = valid ? gates[(size_t)sc * E + ec] : 0.f;
+    const int i1 = idx[2 * sc], i2 = idx[2 * sc + 1];
+    const bool k1 = loc[2 * sc] < C, k2 = loc[2 * sc + 1] < C;
+    const float gi1 = __shfl(g, tk * 32 + i1, 64), gi2 = __shfl(g, tk * 32 + i2, 64);
+    const float g1 = k1 ? gi1 : 0.f, g2 = k2 ? gi2 : 0.f;
+    const float dw1 = d_weight[2 * sc], dw2 = d_weight[2 * sc + 1];
+    const float sum = g1 + g2;
+    float dg1, dg2;
+    if (sum >= kEps) {  // clamp inactive: w_k = g_k / (g1 + g2)
+      const float inv2 = 1.f / (sum * sum);
+      dg1 = (dw1 - dw2) * g2 * inv2;
+      dg2 = (dw2 - dw1) * g1 * inv2;
+    } else {  // clamp active: w_k = g_k / eps
+      dg1 = dw1 / kEps;
+      dg2 = dw2 / kEps;
+    }
+    if (!k1) dg1 = 0.f;
+    if (!k2) dg2 = 0.f;
+    float dg = aux;
+    if (e == i1) dg += dg1;
+    if (e == i2) dg += dg2;
+    float dot = g * dg;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    if (valid) dlogits[(size_t)s * E + e] = g * (dg - dot);
   }
 }
 
@@ -706,11 +847,17 @@ extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int S,
   float* gsum = reinterpret_cast<float*>(ws + w.gsum);
   int32_t* tot = reinterpret_cast<int32_t*>(ws + w.tot);
   hipStream_t st = S_(stream);
-  const int use_tile = E <= 128 ? 1 : 0;
-  const size_t lds1 = use_tile ? (size_t)kGateBlock * (E + 1) * 4 : 0;
-  hipLaunchKernelGGL(gate_select_kernel, dim3(w.nblk), dim3(kGateBlock), lds1, st, logits, noise, S, E, gates, idx,
-                     hist, rank, gsum, slot_token, E * C, use_tile);
-  EVE_CHECK_LAUNCH("gate_select_kernel");
+  if (E <= 32) {
+    hipLaunchKernelGGL(gate_select32_kernel, dim3(w.nblk), dim3(256), 0, st, logits, noise, S, E, gates, idx, hist, rank,
+                       gsum, slot_token, E * C);
+    EVE_CHECK_LAUNCH("gate_select32_kernel");
+  } else {
+    const int use_tile = E <= 128 ? 1 : 0;
+    const size_t lds1 = use_tile ? (size_t)kGateBlock * (E + 1) * 4 : 0;
+    hipLaunchKernelGGL(gate_select_kernel, dim3(w.nblk), dim3(kGateBlock), lds1, st, logits, noise, S, E, gates, idx,
+                       hist, rank, gsum, slot_token, E * C, use_tile);
+    EVE_CHECK_LAUNCH("gate_select_kernel");
+  }
   const size_t lds2 = (size_t)3 * E * 4;
   hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(1024), lds2, st, hist, boff, gsum, tot, exp_counts, rows, l_aux, S,
                      E, C, w.nblk);
@@ -726,6 +873,13 @@ extern "C" int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const i
                                  void* stream) {
   EVE_REQUIRE(gates && idx && loc && d_weight && exp_counts && dlogits, EVE_ERR_ARG, "eve_gate_top2_bwd: null pointer");
   EVE_REQUIRE(S > 0 && E > 0 && C > 0, EVE_ERR_ARG, "eve_gate_top2_bwd: bad shape");
+  if (E <= 32) {
+    const int grid = max(1, min(ceil_div(S, 8), 4096));
+    hipLaunchKernelGGL(gate_bwd32_kernel, dim3(grid), dim3(256), 0, S_(stream), gates, idx, loc, d_weight, d_l_aux,
+                       exp_counts, S, E, C, dlogits);
+    EVE_CHECK_LAUNCH("gate_bwd32_kernel");
+    return EVE_OK;
+  }
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(S, 256)), dim3(256), 0, S_(stream), gates, idx, loc, d_weight,
                      d_l_aux, exp_counts, S, E, C, dlogits);
   EVE_CHECK_LAUNCH("gate_bwd_kernel");
