@@ -170,16 +170,26 @@ def main():
     # kept assignments of the last step (exact K for the algorithmic flop count)
     kept = int((moe.moe.last_slot >= 0).sum().item())
     ffn_ms = prof.get("eve_ffn_fwd", (0.0, 0))[0] + prof.get("eve_ffn_bwd", (0.0, 0))[0]
-    launches = 6 * args.steps  # 2 forward + 4 backward grouped GEMMs per step, 2*M*I*K flops each
-    flops_per_launch = 2.0 * M * I * kept
+    # Per step: 6 grouped GEMMs of 2*M*I*K flops each in 5 launches (the two weight-gradient GEMMs share one).
+    launches = 5 * args.steps
+    flops_per_launch = 6.0 / 5.0 * 2.0 * M * I * kept
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
     roofline = None
     if ffn_ms > 0:
         avg_ms = ffn_ms / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
-                    "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                    "traffic": None, "kernel": "grouped expert-FFN GEMM (6 launches/step)",
-                    "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch}
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, "profiles", "r01_gemm_traffic.json")
+        if args.dtype == "bf16" and args.model == "base" and B == 64 and os.path.exists(tpath):
+            # HBM bytes per launch from separate rocprofv3 --pmc passes of this workload (FETCH_SIZE doubled as the
+            # gfx950 guide prescribes, WRITE_SIZE); counters cannot be read live from inside the process
+            traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_gemm_traffic.json"
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "grouped expert-FFN GEMM (eve::grouped_gemm_pp, 5 launches/step computing 6 GEMMs)",
+                    "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch,
+                    "timing": "HIP events on the launch stream around eve_ffn_fwd / eve_ffn_bwd over the K steps"}
 
     if rank == 0:
         line = {
