@@ -69,7 +69,8 @@ struct MfmaDesc {
 
 struct MfmaPair {
   MfmaDesc d[2];
-  int n0;  // blocks of d[0]; a multiple of 8 (the XCD-aware tile order counts from each problem's first block)
+  int n0;      // blocks (tiles) of d[0]; a multiple of 8 (the XCD-aware tile order counts from each problem's first block)
+  int ntotal;  // tiles of both problems (persistent kernel: the grid is smaller and walks them)
 };
 
 // In-kernel cycle stamps, compiled only into the diagnostic build; they go to a buffer of their own.
@@ -701,6 +702,315 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 }
 
 
+// ------------------------------------------------------------------ persistent ping-pong kernel
+// The schedule of grouped_gemm_pp, but a workgroup walks tiles gb = blockIdx.x, + gridDim.x, ... and the
+// operand ring never drains: the fetch cursor simply runs on into the next tile, so a tile's first
+// sub-tiles are already in LDS when its predecessor's epilogue ends (a fresh workgroup spends ~5 k
+// cycles fetching them cold).  The epilogue is one more phase per half, "E":
+//     waves 0-3:  ... L(n-1) | M(n-1) |   E    | L'(0) | M'(0) ...
+//     waves 4-7:  ... M(n-2) | L(n-1) | M(n-1) |   E   | L'(0) ...
+// It stages 16-row half slabs (4 waves x 4.25 KiB) in the one ring slot that is free during both E
+// phases -- the slot of the finished tile's last B sub-tile, which waves 4-7 refill only in their L'(0),
+// after their own E -- or behind the ring where LDS allows (the 32-deep weight-gradient ring).
+// Single K segment only (weight gradients under expert parallelism use grouped_gemm_pp).
+struct PTile { int which, z, m0, n0, mext, nk, kext; };
+
+// Epilogue of one wave's 32*WR x 64 outputs through a wave-private [16][EPI_LD] fp32 image.
+template <int EPI, int ACT, int WR>
+__device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN], float* ep, const MfmaDesc& d, int z,
+                                                   int e_out, int m0, int n0, int mext, int wave, int lane) {
+  const int wm = wave >> 2, wn = wave & 3;
+  bf16_t* Cg = d.C ? d.C + (size_t)z * d.c_g : nullptr;
+  bf16_t* C2g = d.C2 ? d.C2 + (size_t)z * d.c_g : nullptr;
+  const bf16_t* Zg = d.Zin ? d.Zin + (size_t)z * d.c_g : nullptr;
+  float bv[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    bv[j] = 0.f;
+    if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT)
+      bv[j] = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * 32 + (lane & 31)]);
+  }
+  const int irow = lane >> 3, ich = lane & 7;
+  const int ncol = n0 + wn * 64 + ich * 8;
+  const int mbase = m0 + wm * (WR * 32);
+  uint4 zbuf[2][2];
+  auto load_z = [&](int q, uint4 (&dst)[2]) {  // half slab q: rows mbase + 16 q ..
+    if constexpr (EPI == MEPI_DACT) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int m = min(mbase + q * 16 + it * 8 + irow, mext - 1);
+        dst[it] = *reinterpret_cast<const uint4*>(Zg + (size_t)m * d.ldc + ncol);
+      }
+    }
+  };
+  load_z(0, zbuf[0]);
+  const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 2 * WR; ++q) {
+    const int i = q >> 1, hv = q & 1;
+    if (q + 1 < 2 * WR) load_z(q + 1, zbuf[(q + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = hv * 8 + rr;
+        const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh;
+        ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 8 + irow;
+      const int m = mbase + q * 16 + row;
+      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8 + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const size_t o = (size_t)m * d.ldc + ncol;
+      if constexpr (EPI == MEPI_BIAS_ACT) {
+        if (Cg && m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
+        if (m < mext) *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
+      } else {
+        if constexpr (EPI == MEPI_DACT) {
+          const uint32_t* w = &zbuf[q & 1][it].x;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
+        }
+        if (m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
+__global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 64 * WR, KI = BKI / 16, NSLOT = 5;
+  static_assert(WR == 4 || (WR == 3 && !A_COL && !WGRAD), "192-row tiles: row-major A only");
+  static_assert(!BIAS_GRAD || (A_COL && BKI == 32 && WR == 4), "bias gradient: 32-deep k-major A tiles");
+  constexpr int kSub = 256 * BKI * 2;
+  constexpr int kRing = NSLOT * kSub;
+  constexpr int kStageWave = 16 * EPI_LD * 4;
+  constexpr bool kStageInRing = kRing + 8 * kStageWave > 160 * 1024;
+  static_assert(!kStageInRing || !WGRAD, "a tile without K steps (weight gradients only) needs per-wave images");
+  constexpr int NPB = kSub / 1024 / 4;
+  constexpr int NPA = BM * BKI * 2 / 1024 / 4;
+  constexpr int NP = NPB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int h = wave_u >> 2, w4 = wave_u & 3;
+  const int wm = wave >> 2, wn = wave & 3;
+  const unsigned ntotal = (unsigned)pr.ntotal;
+  const int np = h == 0 ? NPB : NPA;
+
+  // tile gb of the launch -> its coordinates; false when the block id maps to no work
+  auto decode = [&](unsigned gb, PTile& T) -> bool {
+    const int which = gb >= (unsigned)pr.n0 ? 1 : 0;
+    const MfmaDesc& d = pr.d[which];
+    const unsigned bid = which ? gb - (unsigned)pr.n0 : gb;
+    const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
+    const int tiles_per_group = tiles_m * tiles_n;
+    const int ngroups = WGRAD ? d.E_local : d.G;
+    const int chunk = (ngroups + 7) >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int p = xcd * chunk + local / tiles_per_group;
+    if (p >= ngroups) return false;
+    const int tile = local % tiles_per_group;
+    int z;
+    if (WGRAD) {
+      z = p;
+    } else {
+      const int ep = d.G / d.E_local;
+      z = (p % ep) * d.E_local + p / ep;
+    }
+    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+    int mext = d.Mext;
+    if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
+    if (m0 >= mext) return false;
+    int kext = d.K;
+    if (WGRAD && d.rows) kext = min(kext, d.rows[z]);  // single segment: group == expert
+    T.which = which; T.z = z; T.m0 = m0; T.n0 = n0; T.mext = mext; T.kext = kext; T.nk = (kext + BKI - 1) / BKI;
+    return true;
+  };
+  auto advance = [&](unsigned& gb, PTile& T, bool need_k) -> bool {
+    for (gb += gridDim.x; gb < ntotal; gb += gridDim.x)
+      if (decode(gb, T) && (!need_k || T.nk > 0)) return true;
+    return false;
+  };
+
+  unsigned gb_c = blockIdx.x;
+  PTile cur;
+  bool have = gb_c < ntotal;
+  if (have && !decode(gb_c, cur)) have = advance(gb_c, cur, false);
+  if (!have) return;
+
+  // ---- fetch cursor: my operand (waves 0-3: B, waves 4-7: A) of K step t_f of tile ft
+  unsigned gb_f = gb_c;
+  PTile ft = cur;
+  int t_f = 0;
+  bool f_valid = true;
+  if (ft.nk == 0) f_valid = advance(gb_f, ft, true);
+  __amdgpu_buffer_rsrc_t f_rsrc;
+  uint32_t f_voff0 = 0, f_vstride = 0, f_origin0 = 0, f_ostep = 0;
+  auto set_fetch_desc = [&]() {
+    const MfmaDesc& d = pr.d[ft.which];
+    const int e = WGRAD ? ft.z : ft.z % d.E_local;
+    if (h == 0) {
+      const bf16_t* Bg = d.B + (size_t)(WGRAD ? ft.z : e) * d.b_g;
+      const uint32_t bytes = (uint32_t)(B_COL ? (WGRAD ? ft.kext : d.K) * d.ldb : d.N * d.ldb) * 2u;
+      f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bg), 0, bytes, 0x00020000);
+      f_voff0 = sub_dma_offset0<B_COL, BKI>(d.ldb, w4, lane);
+      f_vstride = sub_dma_stride<B_COL>(d.ldb);
+      f_origin0 = (uint32_t)(B_COL ? ft.n0 : ft.n0 * d.ldb) * 2u;
+      f_ostep = (uint32_t)(B_COL ? BKI * d.ldb : BKI) * 2u;
+    } else {
+      const bf16_t* Ag = d.A + (size_t)ft.z * d.a_g;
+      const uint32_t bytes = (uint32_t)(A_COL ? (WGRAD ? ft.kext : d.K) * d.lda : d.Mext * d.lda) * 2u;
+      f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag), 0, bytes, 0x00020000);
+      f_voff0 = sub_dma_offset0<A_COL, BKI>(d.lda, w4, lane);
+      f_vstride = sub_dma_stride<A_COL>(d.lda);
+      f_origin0 = (uint32_t)(A_COL ? ft.m0 : ft.m0 * d.lda) * 2u;
+      f_ostep = (uint32_t)(A_COL ? BKI * d.lda : BKI) * 2u;
+    }
+  };
+  if (f_valid) set_fetch_desc();
+  // issue my operand's sub-tile of the cursor's K step into ring slot `sl`, then move the cursor on
+  auto fetch_next = [&](int sl) {
+    char* slot = smem + sl * kSub;
+    const uint32_t origin = f_origin0 + (uint32_t)t_f * f_ostep;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (i < np)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsrc, (__attribute__((address_space(3))) void*)(slot + (i * 4 + w4) * 1024),
+                                                 16, f_voff0 + (origin + (uint32_t)i * f_vstride), 0, 0, 0);
+    if (++t_f == ft.nk) {
+      t_f = 0;
+      f_valid = advance(gb_f, ft, true);
+      if (f_valid) set_fetch_desc();
+    }
+  };
+  auto wrap = [](int s) { return s >= NSLOT ? s - NSLOT : s; };
+
+  f32x16 acc[WR][WTN];
+#pragma unroll
+  for (int i = 0; i < WR; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+  // prologue: global steps 0 and 1 -> A(0) slot 0, B(0) slot 1, A(1) slot 2
+  if (f_valid) {
+    if (h == 0) {
+      fetch_next(1);
+    } else {
+      fetch_next(0);
+      if (f_valid) fetch_next(2);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (h == 1) __builtin_amdgcn_s_barrier();  // interval 0: waves 4-7 have nothing to do yet
+  int sl_c = 0;  // ring slot of the A sub-tile of the K step being computed; its B sub-tile is the next slot
+  bf16x8 fa[KI][WR], fb[KI][WTN];
+  for (;;) {
+    const MfmaDesc& d = pr.d[cur.which];
+    const bool do_bias_grad = BIAS_GRAD && cur.n0 == 0;
+    for (int t = 0; t < cur.nk; ++t) {
+      // ---- L phase
+      const char* sa = smem + sl_c * kSub;
+      const char* sb = smem + wrap(sl_c + 1) * kSub;
+#pragma unroll
+      for (int ks = 0; ks < KI; ++ks) {
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[ks][j] = frag_load<B_COL, BN>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) fa[ks][i] = frag_load<A_COL, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
+      }
+      if constexpr (BIAS_GRAD) {
+        if (do_bias_grad) {
+          // column sums of the k-major A tile: wave w owns 16-byte chunks 4w .. 4w+3 (32 columns), lane
+          // (lane & 3) one chunk and (lane >> 2) every 16th k row; reduced inside the wave at the end
+          const int chunk = 4 * wave + (lane & 3);
+#pragma unroll
+          for (int kk = 0; kk < BKI; kk += 16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(sa + col_tile_off<BM>(kk + (lane >> 2), chunk));
+            const uint32_t* w = &v.x;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += bf16_bits_to_f32(w[j >> 1], j & 1);
+          }
+        }
+      }
+      if (f_valid) fetch_next(wrap(sl_c + 3 + h));  // waves 0-3: B of the next step; waves 4-7: A of the one after
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- M phase
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KI; ++ks)
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my fetch has landed (it had the whole M phase)
+      __builtin_amdgcn_s_barrier();
+      sl_c = wrap(sl_c + 2);
+    }
+    // ---- E phase
+    // (behind the ring every wave has its own image: after a tile without K steps -- an expert that
+    // received no rows -- waves 0-3 are in their next E phase while waves 4-7 are still in this one)
+    float* ep = reinterpret_cast<float*>(kStageInRing ? smem + wrap(sl_c + 4) * kSub + w4 * kStageWave
+                                                      : smem + kRing + wave_u * kStageWave);
+    tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0, cur.n0, cur.mext,
+                                     wave, lane);
+    if constexpr (BIAS_GRAD) {
+      if (do_bias_grad) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = bsum[j];
+          v += __shfl_xor(v, 4, 64);
+          v += __shfl_xor(v, 8, 64);
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          bsum[j] = v;
+        }
+        if (lane < 4)
+          *reinterpret_cast<uint4*>(d.dbias + (size_t)cur.z * d.Mext + cur.m0 + (4 * wave + lane) * 8) = pack8(bsum);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    have = advance(gb_c, cur, false);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my staging image is free again
+    // waves 4-7 run one phase behind: their last E phase has no partner phase and no barrier
+    if (!have) {
+      if (h == 0) __builtin_amdgcn_s_barrier();
+      break;
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+
 bool ffn_mfma_supported(int M, int I) { return M % 256 == 0 && I % 256 == 0; }
 
 template <int BM, int NS, bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
@@ -740,6 +1050,28 @@ static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
   return EVE_OK;
 }
 
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+// Debug knob for A/B timing: EVE_FFN_KERNEL=lockstep selects the older 256-row kernel.
+static bool use_pingpong() {
+  const char* v = getenv("EVE_FFN_KERNEL");
+  return !(v && v[0] == 'l');
+}
+
+// EVE_FFN_PERSIST=0 selects the one-tile-per-workgroup ping-pong kernel.
+static bool use_persistent() {
+  const char* v = getenv("EVE_FFN_PERSIST");
+  return !(v && v[0] == '0');
+}
+
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI, int WR = 4>
 static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc* d2 = nullptr) {
   constexpr int kEpi = 8 * 32 * EPI_LD * 4;
@@ -752,7 +1084,15 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   pr.d[0] = d;
   pr.d[1] = d2 ? *d2 : d;
   pr.n0 = blocks(d);
-  dim3 grid(pr.n0 + (d2 ? blocks(*d2) : 0));
+  pr.ntotal = pr.n0 + (d2 ? blocks(*d2) : 0);
+  // persistent variant: one workgroup per CU walks the tiles (single K segment only)
+  // (not for the activation epilogues: their E phases are long and VALU-heavy, and run one half after the
+  // other here, where the one-tile kernel overlaps the two halves' epilogues -- measured 4-6 % slower)
+  const bool persist = use_persistent() && EPI != MEPI_BIAS_ACT && EPI != MEPI_DACT && (!WGRAD || d.G == d.E_local) &&
+                       pr.ntotal > cu_count();
+  constexpr int kStage = 8 * 16 * EPI_LD * 4;
+  constexpr int kLdsP = (5 * 256 * BKI * 2 + kStage > 160 * 1024) ? 5 * 256 * BKI * 2 : 5 * 256 * BKI * 2 + kStage;
+  dim3 grid(persist ? (cu_count() / 8) * 8 : pr.ntotal);
 #define EVE_PP_LAUNCH(A)                                                                                     \
   do {                                                                                                       \
     auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                                \
@@ -765,7 +1105,18 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
       }                                                                                                      \
       attr_done = true;                                                                                      \
     }                                                                                                        \
-    hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, pr);                                                 \
+    auto kernp = grouped_gemm_ppp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                           \
+    static bool attrp_done = false;                                                                          \
+    if (persist && !attrp_done) {                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernp), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              kLdsP) != hipSuccess) {                                                        \
+        set_error("ffn_mfma: cannot reserve %d bytes of LDS", kLdsP);                                        \
+        return EVE_ERR_LAUNCH;                                                                               \
+      }                                                                                                      \
+      attrp_done = true;                                                                                     \
+    }                                                                                                        \
+    if (persist) hipLaunchKernelGGL(kernp, grid, dim3(512), kLdsP, st, pr);                                  \
+    else hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, pr);                                            \
   } while (0)
   if constexpr (EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT) {
     switch (act) {
@@ -783,22 +1134,6 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
 #undef EVE_PP_LAUNCH
   EVE_CHECK_LAUNCH("grouped_gemm_pp");
   return EVE_OK;
-}
-
-// Debug knob for A/B timing: EVE_FFN_KERNEL=lockstep selects the older 256-row kernel.
-static bool use_pingpong() {
-  const char* v = getenv("EVE_FFN_KERNEL");
-  return !(v && v[0] == 'l');
-}
-
-static int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
-  }
-  return n;
 }
 
 // Tile choice.  One workgroup fills a CU, so a launch costs about ceil(tiles / CUs) * rows-per-tile:

@@ -36,6 +36,7 @@ fl = 2.0 * a.M * a.I * kept
 def run(variant, iters):
     os.environ["EVE_FFN_KERNEL"] = "lockstep" if variant == "lockstep" else "pingpong"
     os.environ.pop("EVE_FFN_TILE_ROWS", None)
+    os.environ["EVE_FFN_PERSIST"] = "0" if variant == "onetile" else "1"  # onetile: one tile per workgroup
     if variant in ("pp256", "pp192"):  # force the block-tile height of the ping-pong kernel
         os.environ["EVE_FFN_TILE_ROWS"] = variant[2:]
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
