@@ -11,7 +11,8 @@ the C ABI of libeve_moe.so (include/eve_moe.h).
 from .experts import ACT2FN, Experts, MultiwayTransformerMLP, QuickGELU
 from .graph import GraphedTrainStep
 from .layer import MoE
+from .multiway import ModalitySplitFFN
 from .sharded_moe import MOELayer, TopKGate, gumbel_rsample, top2gating
 
-__all__ = ["MoE", "GraphedTrainStep", "MOELayer", "TopKGate", "Experts", "MultiwayTransformerMLP", "QuickGELU", "ACT2FN",
+__all__ = ["MoE", "GraphedTrainStep", "ModalitySplitFFN", "MOELayer", "TopKGate", "Experts", "MultiwayTransformerMLP", "QuickGELU", "ACT2FN",
            "gumbel_rsample", "top2gating"]

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p, c_long
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p, c_long
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeve_moe.so")
@@ -39,6 +39,10 @@ SIGNATURES = {
     "eve_route_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "eve_combine_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "eve_combine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "eve_split_ln_fwd": (c_int, [_P] * 8 + [_I] * 5 + [c_float, _I, _P]),
+    "eve_split_ln_workspace_bytes": (c_size_t, [_I, _I]),
+    "eve_split_ln_bwd": (c_int, [_P] * 8 + [_I] * 6 + [_P, _Z, _P]),
+    "eve_split_permute": (c_int, [_P, _P] + [_I] * 7 + [_P]),
     "eve_ffn_fwd": (c_int, [_P] * 9 + [_I] * 7 + [_P]),
     "eve_ffn_bwd": (c_int, [_P] * 13 + [_I] * 7 + [_P]),
 }

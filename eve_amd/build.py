@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libeve_moe.so")
-SOURCES = ["capi.hip", "gate.hip", "permute.hip", "ffn.hip", "ffn_mfma.hip"]
+SOURCES = ["capi.hip", "gate.hip", "permute.hip", "ffn.hip", "ffn_mfma.hip", "multiway.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -286,19 +286,21 @@ __global__ __launch_bounds__((BM / 128) * 256) void grouped_gemm_mfma(MfmaDesc d
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wm = wave >> 2, wn = wave & 3;
   // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private
-  // L2), so block b and b+8 share an L2.  Every XCD walks a contiguous run of whole groups (sorted
-  // expert-major, so groups that share weights sit on one XCD) and, inside a group, all its tiles
+  // L2), so block b and b+8 share an L2.  Every XCD walks a contiguous run of (group, tile) items --
+  // whole groups when there are at least 8 of them (sorted expert-major, so groups that share weights
+  // sit on one XCD), a slice of a group's tiles when there are fewer -- and, inside a group, its tiles
   // with the row tile varying fastest: the ~32 tiles an XCD runs at a time then share their A row
   // panels and B column panels through its L2 instead of each streaming them from HBM.
   // (Speed only: correctness does not depend on where a block runs.)
   const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
   const int tiles_per_group = tiles_m * tiles_n;
   const int ngroups = WGRAD ? d.E_local : d.G;
-  const int chunk = (ngroups + 7) >> 3;
+  const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;  // each XCD walks a contiguous run of (group, tile) items
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int p = xcd * chunk + local / tiles_per_group;
-  if (p >= ngroups) return;
-  const int tile = local % tiles_per_group;
+  const int item = xcd * per_xcd + local;
+  if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
+  const int p = item / tiles_per_group;
+  const int tile = item % tiles_per_group;
   int z;
   if (WGRAD) {
     z = p;
@@ -517,11 +519,12 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
   const int tiles_per_group = tiles_m * tiles_n;
   const int ngroups = WGRAD ? d.E_local : d.G;
-  const int chunk = (ngroups + 7) >> 3;
+  const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
   const int xcd = bid & 7, local = bid >> 3;
-  const int p = xcd * chunk + local / tiles_per_group;
-  if (p >= ngroups) return;
-  const int tile = local % tiles_per_group;
+  const int item = xcd * per_xcd + local;
+  if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
+  const int p = item / tiles_per_group;
+  const int tile = item % tiles_per_group;
   int z;
   if (WGRAD) {
     z = p;
@@ -816,11 +819,12 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
     const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
     const int tiles_per_group = tiles_m * tiles_n;
     const int ngroups = WGRAD ? d.E_local : d.G;
-    const int chunk = (ngroups + 7) >> 3;
+    const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
     const int xcd = bid & 7, local = bid >> 3;
-    const int p = xcd * chunk + local / tiles_per_group;
-    if (p >= ngroups) return false;
-    const int tile = local % tiles_per_group;
+    const int item = xcd * per_xcd + local;
+    if (local >= per_xcd || item >= ngroups * tiles_per_group) return false;
+    const int p = item / tiles_per_group;
+    const int tile = item % tiles_per_group;
     int z;
     if (WGRAD) {
       z = p;
@@ -1017,7 +1021,7 @@ template <int BM, int NS, bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS
 static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
   using C_ = Cfg<BM, NS>;
   const int ngroups = WGRAD ? d.E_local : d.G;
-  dim3 grid(8 * ceil_div(ngroups, 8) * (d.N / BN) * ceil_div(d.Mext, BM));
+  dim3 grid(8 * ceil_div(ngroups * (d.N / BN) * ceil_div(d.Mext, BM), 8));
 #define EVE_MFMA_LAUNCH(A)                                                                                   \
   do {                                                                                                       \
     auto kern = grouped_gemm_mfma<BM, NS, A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD>;                           \
@@ -1078,7 +1082,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   constexpr int kLds = 5 * 256 * BKI * 2 > kEpi ? 5 * 256 * BKI * 2 : kEpi;
   auto blocks = [](const MfmaDesc& q) {
     const int ngroups = WGRAD ? q.E_local : q.G;
-    return 8 * ceil_div(ngroups, 8) * (q.N / BN) * ceil_div(q.Mext, 64 * WR);
+    return 8 * ceil_div(ngroups * (q.N / BN) * ceil_div(q.Mext, 64 * WR), 8);
   };
   MfmaPair pr;
   pr.d[0] = d;

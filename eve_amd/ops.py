@@ -264,3 +264,40 @@ def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int):
     PROFILE.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),
               _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _stream())
     return dx, dw1, db1, dw2, db2
+
+
+# ------------------------------------------------ hard modality split of the non-MoE layers
+def split_ln_fwd(h, gamma_v, beta_v, gamma_t, beta_t, n_vis: int, R: int, eps: float):
+    """h [B,T,M] -> (xg [2,R,M], mean [S], rstd [S]); see include/eve_moe.h."""
+    _chk(h, "hidden")
+    for t, n in ((gamma_v, "gamma_v"), (beta_v, "beta_v"), (gamma_t, "gamma_t"), (beta_t, "beta_t")):
+        _chk(t, n, h.dtype)
+    B, T, M = h.shape
+    xg = torch.empty(2, R, M, dtype=h.dtype, device=h.device)
+    mean = torch.empty(B * T, dtype=torch.float32, device=h.device)
+    rstd = torch.empty(B * T, dtype=torch.float32, device=h.device)
+    PROFILE.call("eve_split_ln_fwd", _p(h), _p(gamma_v), _p(beta_v), _p(gamma_t), _p(beta_t), _p(xg), _p(mean), _p(rstd),
+                 B, T, n_vis, R, M, float(eps), _dt(h), _stream())
+    return xg, mean, rstd
+
+
+def split_ln_bwd(dxg, h, mean, rstd, gamma_v, gamma_t, n_vis: int):
+    """-> (dh [B,T,M], dparams [4,M] fp32 = dgamma_v, dbeta_v, dgamma_t, dbeta_t)."""
+    _chk(dxg, "dxg", h.dtype), _chk(h, "hidden")
+    B, T, M = h.shape
+    R = dxg.shape[1]
+    dh = torch.empty_like(h)
+    dparams = torch.empty(4, M, dtype=torch.float32, device=h.device)
+    nbytes = _lib.load().eve_split_ln_workspace_bytes(B * T, M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+    PROFILE.call("eve_split_ln_bwd", _p(dxg), _p(h), _p(mean), _p(rstd), _p(gamma_v), _p(gamma_t), _p(dh), _p(dparams),
+                 B, T, n_vis, R, M, _dt(h), _p(ws), nbytes, _stream())
+    return dh, dparams
+
+
+def split_permute(src, B: int, T: int, n_vis: int, R: int, to_groups: bool):
+    _chk(src, "src")
+    M = src.shape[-1]
+    dst = torch.empty((2, R, M) if to_groups else (B, T, M), dtype=src.dtype, device=src.device)
+    PROFILE.call("eve_split_permute", _p(src), _p(dst), B, T, n_vis, R, M, 1 if to_groups else 0, _dt(src), _stream())
+    return dst

@@ -175,6 +175,34 @@ int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, con
                 void* dz, void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G,
                 int E_local, int R, int M, int I, int act, int dtype, void* stream);
 
+/* ------------------------------------------------- hard modality split of the non-MoE layers
+ * Reference models/multiway_transformer.py:366-370: vision positions [:, :n_vis] go through
+ * norm2_imag + mlp_imag, the last T - n_vis positions through norm2_text + mlp_text, results concatenated
+ * (:386-387 / :402-403 are the single-modality cases n_vis = T / n_vis = 0).  The two MLPs run as one
+ * eve_ffn_fwd/bwd with two groups on a [2, R, M] buffer: token (b,t), t < n_vis, is row b*n_vis + t of
+ * group 0, otherwise row b*(T-n_vis) + (t-n_vis) of group 1; R >= B * max(n_vis, T-n_vis). */
+
+/* xg[group rows] = LayerNorm(h[b,t]) with the token's modality's affine (gamma/beta have h's dtype), fp32
+ * statistics, biased variance, eps inside the square root as torch.nn.LayerNorm; mean / rstd [B*T] fp32 are
+ * saved for the backward.  M <= 1024. */
+int eve_split_ln_fwd(const void* h, const void* gamma_v, const void* beta_v, const void* gamma_t, const void* beta_t,
+                     void* xg, float* mean, float* rstd, int B, int T, int n_vis, int R, int M, float eps, int dtype,
+                     void* stream);
+
+size_t eve_split_ln_workspace_bytes(int S, int M);
+
+/* Backward of eve_split_ln_fwd: dxg [2,R,M] in; dh [B*T, M] and dparams [4][M] fp32 =
+ * (dgamma_v, dbeta_v, dgamma_t, dbeta_t) out (two-stage fixed-order reduction, deterministic). */
+int eve_split_ln_bwd(const void* dxg, const void* h, const float* mean, const float* rstd, const void* gamma_v,
+                     const void* gamma_t, void* dh, float* dparams, int B, int T, int n_vis, int R, int M, int dtype,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Row permutation between token order [B*T, M] and the group buffer [2, R, M]: to_groups != 0 copies token
+ * rows into their group rows, 0 copies group rows back to token order (the reference's slices and
+ * torch.cat at :366-370).  It is its own transpose, so each direction is the other's backward. */
+int eve_split_permute(const void* src, void* dst, int B, int T, int n_vis, int R, int M, int to_groups, int dtype,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

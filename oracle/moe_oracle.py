@@ -285,3 +285,34 @@ def synth_hidden(B: int, T: int, M: int, seed: int, dtype=torch.float32) -> torc
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, T, M, generator=g)
     return torch.nn.functional.layer_norm(x, (M,)).to(dtype)
+
+
+# ------------------------------------------------ hard modality split of the non-MoE layers
+def make_split_params(M: int, I: int, *, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """norm2_imag / norm2_text affine (perturbed away from the 1/0 init so that they matter) and the two MLPs,
+    index 0 = imag, 1 = text."""
+    g = torch.Generator().manual_seed(seed)
+    p = {
+        "ln_w": 1.0 + 0.2 * torch.randn(2, M, generator=g), "ln_b": 0.1 * torch.randn(2, M, generator=g),
+        "w1": torch.randn(2, I, M, generator=g) * M ** -0.5, "b1": 0.1 * torch.randn(2, I, generator=g),
+        "w2": torch.randn(2, M, I, generator=g) * I ** -0.5, "b2": 0.1 * torch.randn(2, M, generator=g),
+    }
+    return {k: v.to(dtype) for k, v in p.items()}
+
+
+def split_ffn_forward(h: torch.Tensor, p: Dict[str, torch.Tensor], num_text_tokens: int, mode: str = "vl",
+                      eps: float = 1e-6) -> torch.Tensor:
+    """models/multiway_transformer.py:366-370 ('vl'), :386-387 ('vision'), :402-403 ('text')."""
+    M = h.shape[-1]
+
+    def branch(x, i):
+        x = torch.nn.functional.layer_norm(x, (M,), p["ln_w"][i], p["ln_b"][i], eps)
+        return expert_ffn(x, p["w1"][i], p["b1"][i], p["w2"][i], p["b2"][i])
+
+    if mode == "vision":
+        return branch(h, 0)
+    if mode == "text":
+        return branch(h, 1)
+    hidden_vision = h[:, :-num_text_tokens]
+    hidden_lang = h[:, -num_text_tokens:]
+    return torch.cat([branch(hidden_vision, 0), branch(hidden_lang, 1)], dim=1)
