@@ -12,6 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p, c_lon
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeve_moe.so")
+LIB_PATH = os.environ.get("EVE_MOE_LIB", LIB_PATH)  # A/B experiments: an alternative build of the same ABI
 
 F32, BF16 = 0, 1
 MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3

@@ -20,6 +20,7 @@
 #include "ffn_mfma.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "act.h"
 
@@ -31,6 +32,15 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 enum { MEPI_STORE = 0, MEPI_BIAS = 1, MEPI_BIAS_ACT = 2, MEPI_DACT = 3 };
+
+// MFMA shape of the ping-pong kernels: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same flops
+// per cycle and the same fragment traffic; the chip holds a higher clock with the 16x16 shape under load)
+#ifndef EVE_MFMA16
+#define EVE_MFMA16 0
+#endif
+constexpr bool kM16 = EVE_MFMA16 != 0;
+constexpr int kTR = kM16 ? 16 : 32;   // edge of one MFMA output tile
+constexpr int kKS = kM16 ? 32 : 16;   // K depth of one MFMA
 
 constexpr int BN = 256, BK = 64;
 constexpr int WTM = 4, WTN = 2;  // MFMA tiles per wave: 128 x 64 outputs
@@ -160,6 +170,32 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int r0, int ks, in
   }
 }
 
+// Same for v_mfma_f32_16x16x32_bf16: 16-row (or 16-column) sub-tile starting at r0, K sub-step ks (32 deep);
+// lane l supplies row / column l & 15 and k = 8 (l >> 4) .. + 8.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <bool M16> using acc_tile_t = typename std::conditional<M16, f32x4, f32x16>::type;
+template <bool COL, int W>
+__device__ __forceinline__ bf16x8 frag_load16(const char* tile, int r0, int ks, int lane) {
+  if constexpr (!COL) {
+    const int row = r0 + (lane & 15);
+    const int c = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + row_tile_off(row, c));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int e = r0 + 4 * p;
+    s16x4 v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = ks * 32 + 8 * g + 4 * r + q;
+      const int off = col_tile_off<W>(k, e >> 3) + ((e & 7) << 1);
+      v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) char*)(tile + off));
+    }
+    s16x8 w = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, w);
+  }
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t w, int hi) {
   return __uint_as_float(hi ? (w & 0xffff0000u) : (w << 16));
 }
@@ -183,20 +219,21 @@ template <int PER> __device__ __forceinline__ void wait_tiles_in_flight(int tile
 // Epilogue of one block tile.  Per wave, one 32-row slab (MFMA row tile i) at a time through a private
 // fp32 LDS image, so that global stores are 16 B per lane along rows.  Only the wave itself touches
 // its image; waves are laid out (wave >> 2) x (wave & 3) over 128 x 64 outputs each.
-template <int EPI, int ACT, int WR = WTM>
-__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WR][WTN], char* smem, const MfmaDesc& d, int z, int e_out,
+template <int EPI, int ACT, int WR = WTM, bool M16 = false>
+__device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ? 2 * WR : WR][M16 ? 4 : WTN], char* smem, const MfmaDesc& d, int z, int e_out,
                                               int m0, int n0, int mext, int wave, int lane) {
   const int wm = wave >> 2, wn = wave & 3;
   float* ep = reinterpret_cast<float*>(smem) + wave * 32 * EPI_LD;
   bf16_t* Cg = d.C ? d.C + (size_t)z * d.c_g : nullptr;
   bf16_t* C2g = d.C2 ? d.C2 + (size_t)z * d.c_g : nullptr;
   const bf16_t* Zg = d.Zin ? d.Zin + (size_t)z * d.c_g : nullptr;
-  float bv[WTN];
+  constexpr int NTN = M16 ? 4 : WTN, TW = M16 ? 16 : 32;  // column tiles per wave and their width
+  float bv[NTN];
 #pragma unroll
-  for (int j = 0; j < WTN; ++j) {
+  for (int j = 0; j < NTN; ++j) {
     bv[j] = 0.f;
     if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT)
-      bv[j] = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * 32 + (lane & 31)]);
+      bv[j] = to_f32<bf16_t>(d.bias[(size_t)e_out * d.N + n0 + wn * 64 + j * TW + (lane & (TW - 1))]);
   }
   // item `it` of a slab: lane -> (row it*8 + lane/8, 8 columns from (lane%8)*8)
   const int irow = lane >> 3, ich = lane & 7;
@@ -218,14 +255,24 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[WR][WTN], char
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     if (i + 1 < WR) load_z(i + 1, zbuf[(i + 1) & 1]);
-    const int c = lane & 31, h = lane >> 5;
+    if constexpr (M16) {  // D of 16x16: column lane & 15, rows 4 (lane >> 4) + r
+      const int c = lane & 15, g4 = 4 * (lane >> 4);
 #pragma unroll
-    for (int j = 0; j < WTN; ++j)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
-      }
+        for (int j = 0; j < NTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ep[(ii * 16 + g4 + r) * EPI_LD + j * 16 + c] = acc[2 * i + ii][j][r] + bv[j];
+    } else {
+      const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < NTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -504,7 +551,8 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   const unsigned bid = second ? blockIdx.x - (unsigned)pr.n0 : blockIdx.x;
   // WR = MFMA row tiles per wave: 4 -> 256-row block tiles, 3 -> 192-row tiles (row-major A only),
   // which pack N = 768 problems on 256 CUs without a half-empty last wave of tiles.
-  constexpr int BM = 64 * WR, KI = BKI / 16, NSLOT = 5;
+  constexpr int BM = 64 * WR, KI = BKI / kKS, NSLOT = 5;
+  constexpr int NTM = WR * 32 / kTR, NTN = 64 / kTR;  // MFMA tiles per wave
   static_assert(WR == 4 || (WR == 3 && !A_COL && !WGRAD), "192-row tiles: row-major A only");
   constexpr int kSub = 256 * BKI * 2;       // bytes of one ring slot (a 256 x BKI sub-tile)
   constexpr int NPB = kSub / 1024 / 4;      // DMA instructions per wave per B sub-tile
@@ -537,13 +585,13 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
   if (m0 >= mext) return;
 
-  f32x16 acc[WR][WTN];
+  acc_tile_t<kM16> acc[NTM][NTN];
 #pragma unroll
-  for (int i = 0; i < WR; ++i)
+  for (int i = 0; i < NTM; ++i)
 #pragma unroll
-    for (int j = 0; j < WTN; ++j)
+    for (int j = 0; j < NTN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < (kM16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
   float bsum[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
@@ -587,7 +635,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
                                                voff0 + (origin + (uint32_t)i * vstride), 0, 0, 0);
     };
 
-    bf16x8 fa[KI][WR], fb[KI][WTN];
+    bf16x8 fa[KI][NTM], fb[KI][NTN];
     // L phase: fragment reads of tile t, interleaved with the DMA pieces of the tile fetched now
     auto load_phase = [&](int sl_a, bool fetch, int tf, int t) {
       const int sl_b = sl_a + 1 >= NSLOT ? sl_a + 1 - NSLOT : sl_a + 1;
@@ -607,9 +655,12 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #pragma unroll
       for (int ks = 0; ks < KI; ++ks) {
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) fb[ks][j] = frag_load<B_COL, BN>(sb, wn * 64 + j * 32, ks, lane);
+        for (int j = 0; j < NTN; ++j)
+          fb[ks][j] = kM16 ? frag_load16<B_COL, BN>(sb, wn * 64 + j * 16, ks, lane) : frag_load<B_COL, BN>(sb, wn * 64 + j * 32, ks, lane);
 #pragma unroll
-        for (int i = 0; i < WR; ++i) fa[ks][i] = frag_load<A_COL, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
+        for (int i = 0; i < NTM; ++i)
+          fa[ks][i] = kM16 ? frag_load16<A_COL, BM>(sa, wm * (WR * 32) + i * 16, ks, lane)
+                           : frag_load<A_COL, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
         if constexpr (kInterleave) {
           if (fetch) {
 #pragma unroll
@@ -673,10 +724,12 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #pragma unroll
       for (int ks = 0; ks < KI; ++ks)
 #pragma unroll
-        for (int i = 0; i < WR; ++i)
+        for (int i = 0; i < NTM; ++i)
 #pragma unroll
-          for (int j = 0; j < WTN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NTN; ++j) {
+            if constexpr (kM16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+          }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       EVE_STAMP(3);
@@ -692,7 +745,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #ifdef EVE_PP_STAMP
   { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 60 ? c_ : stamp_v; }
 #endif
-  tile_epilogue<EPI, ACT, WR>(acc, smem, d, z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+  tile_epilogue<EPI, ACT, WR, kM16>(acc, smem, d, z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
   if constexpr (BIAS_GRAD) {
     if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, z, m0);  // block-uniform
   }
