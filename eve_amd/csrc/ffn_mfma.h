@@ -11,6 +11,9 @@ int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, 
 
 int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2, void* dz,
                  void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G, int E_local, int R,
-                 int M, int I, int act, hipStream_t st);
+                 int M, int I, int act, void* workspace, size_t workspace_bytes, hipStream_t st);
+
+// bytes of scratch ffn_bwd_mfma needs for these shapes (0 when the weight gradients are not split along K)
+size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int M, int I);
 
 }  // namespace eve

@@ -31,7 +31,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-enum { MEPI_STORE = 0, MEPI_BIAS = 1, MEPI_BIAS_ACT = 2, MEPI_DACT = 3 };
+enum { MEPI_STORE = 0, MEPI_BIAS = 1, MEPI_BIAS_ACT = 2, MEPI_DACT = 3, MEPI_STORE_F32 = 4 };
 
 // MFMA shape of the ping-pong kernels: 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (same flops
 // per cycle and the same fragment traffic; the chip holds a higher clock with the 16x16 shape under load)
@@ -71,6 +71,11 @@ struct MfmaDesc {
   int Mext, N, K;
   int G, E_local;
   const int32_t* rows;
+  // weight-gradient split-K (ksplit > 1): split j of expert e accumulates a slice of the K (row) range into
+  // fp32 partials Cpart[j][e][Mext][N] / dbias_part[j][e][Mext]; wgrad_reduce_kernel sums the splits in order
+  int ksplit;
+  float* Cpart;
+  float* dbias_part;
 #ifdef EVE_PP_STAMP
   unsigned long long* dbg;  // diagnostic build (tools/pp_stamps.hip): [block 0 / 1000][wave 8][64] cycle stamps (low 32 bits)
   int same_tile;            // diagnostic: every K step fetches K tile 0 (everything hits in L2)
@@ -288,6 +293,12 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
         if (m < mext) *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
+      } else if constexpr (EPI == MEPI_STORE_F32) {
+        if (m < mext) {  // fp32 partial of a split-K weight gradient; z = split * E_local + expert
+          float* o32 = d.Cpart + (size_t)z * d.c_g + o;
+          *reinterpret_cast<float4*>(o32) = lo;
+          *reinterpret_cast<float4*>(o32 + 4) = hi;
+        }
       } else {
         if constexpr (EPI == MEPI_DACT) {
           const uint32_t* w = &zbuf[i & 1][it].x;
@@ -317,7 +328,8 @@ __device__ __forceinline__ void bias_grad_store(const float (&bsum)[8], char* sm
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < RG; ++r) s += red[r * BM + threadIdx.x];
-    d.dbias[(size_t)z * d.Mext + m0 + threadIdx.x] = static_cast<bf16_t>(s);
+    if (d.ksplit > 1) d.dbias_part[(size_t)z * d.Mext + m0 + threadIdx.x] = s;  // z = split * E_local + expert
+    else d.dbias[(size_t)z * d.Mext + m0 + threadIdx.x] = static_cast<bf16_t>(s);
   }
 }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -541,7 +553,7 @@ __device__ __forceinline__ uint32_t sub_dma_offset0(int ld, int w4, int lane) {
 template <bool COL> __device__ __forceinline__ uint32_t sub_dma_stride(int ld) { return (uint32_t)(COL ? 8 : 32) * (uint32_t)ld * 2u; }
 
 template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
-__global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
+__device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // Two independent problems of the same kind may share a launch (the two weight-gradient GEMMs of a
   // backward pass): blocks [0, n0) work on the first, the rest on the second, so that the tail of the
@@ -558,7 +570,6 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   constexpr int NPB = kSub / 1024 / 4;      // DMA instructions per wave per B sub-tile
   constexpr int NPA = BM * BKI * 2 / 1024 / 4;  // ... per A sub-tile
   constexpr int NP = NPB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int h = wave_u >> 2, w4 = wave_u & 3;  // half (= row half of the tile), index inside the half
@@ -566,16 +577,18 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   // XCD-aware tile order (see grouped_gemm_mfma)
   const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
   const int tiles_per_group = tiles_m * tiles_n;
-  const int ngroups = WGRAD ? d.E_local : d.G;
+  const int nsplit = WGRAD ? max(d.ksplit, 1) : 1;
+  const int ngroups = WGRAD ? d.E_local * nsplit : d.G;
   const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
   const int xcd = bid & 7, local = bid >> 3;
   const int item = xcd * per_xcd + local;
   if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
   const int p = item / tiles_per_group;
   const int tile = item % tiles_per_group;
-  int z;
+  int z, split = 0;
   if (WGRAD) {
-    z = p;
+    z = p % d.E_local;   // p = split * E_local + expert
+    split = p / d.E_local;
   } else {
     const int ep = d.G / d.E_local;
     z = (p % ep) * d.E_local + p / ep;
@@ -606,13 +619,29 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
   const uint32_t vstride = h == 0 ? sub_dma_stride<B_COL>(d.ldb) : sub_dma_stride<A_COL>(d.lda);
   const int np = h == 0 ? NPB : NPA;  // pieces per wave of my operand's sub-tile
 
+  // K range of this block: all segments (groups that share the expert) and all their rows, or -- split-K --
+  // a run of whole segments (ksplit <= nseg) / one slice of one segment's rows (ksplit > nseg)
   const int nseg = WGRAD ? d.G / d.E_local : 1;
-  for (int seg = 0; seg < nseg; ++seg) {
+  int seg_lo = 0, seg_hi = nseg, kbase = 0, kchunk = d.K;
+  if (WGRAD && nsplit > 1) {
+    if (nsplit <= nseg) {
+      seg_lo = split * (nseg / nsplit);
+      seg_hi = seg_lo + nseg / nsplit;
+    } else {
+      const int rs = nsplit / nseg;  // row slices per segment
+      seg_lo = split / rs;
+      seg_hi = seg_lo + 1;
+      kchunk = ((d.K + rs - 1) / rs + BKI - 1) / BKI * BKI;
+      kbase = (split % rs) * kchunk;
+    }
+  }
+  for (int seg = seg_lo; seg < seg_hi; ++seg) {
     const int g = WGRAD ? seg * d.E_local + z : z;
     const int e = WGRAD ? z : z % d.E_local;
     int kext = d.K;
     if (WGRAD && d.rows) kext = min(kext, d.rows[g]);
-    const int nk = (kext + BKI - 1) / BKI;
+    kext = min(kext, kbase + kchunk);  // (first row past my slice; kbase = 0 and kchunk = K without row slices)
+    const int nk = kext > kbase ? (kext - kbase + BKI - 1) / BKI : 0;
     if (nk == 0) continue;
     const bf16_t* Ag = d.A + (size_t)g * d.a_g;
     const bf16_t* Bg = d.B + (size_t)(WGRAD ? g : e) * d.b_g;
@@ -625,8 +654,8 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #ifdef EVE_PP_STAMP
       if (d.same_tile) t = 0;
 #endif
-      if (h == 0) return (uint32_t)(B_COL ? (t * BKI) * d.ldb + n0 : n0 * d.ldb + t * BKI) * 2u;
-      return (uint32_t)(A_COL ? (t * BKI) * d.lda + m0 : m0 * d.lda + t * BKI) * 2u;
+      if (h == 0) return (uint32_t)(B_COL ? (kbase + t * BKI) * d.ldb + n0 : n0 * d.ldb + kbase + t * BKI) * 2u;
+      return (uint32_t)(A_COL ? (kbase + t * BKI) * d.lda + m0 : m0 * d.lda + kbase + t * BKI) * 2u;
     };
     auto my_slot = [&](int t) -> char* { return smem + ((2 * t + (h == 0 ? 1 : 0)) % NSLOT) * kSub; };  // prologue only
     auto dma_piece = [&](char* slot, uint32_t origin, int i) {
@@ -745,9 +774,10 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #ifdef EVE_PP_STAMP
   { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 60 ? c_ : stamp_v; }
 #endif
-  tile_epilogue<EPI, ACT, WR, kM16>(acc, smem, d, z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+  // split-K partials are indexed by (split, expert)
+  tile_epilogue<EPI, ACT, WR, kM16>(acc, smem, d, split * d.E_local + z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
   if constexpr (BIAS_GRAD) {
-    if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, z, m0);  // block-uniform
+    if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, split * d.E_local + z, m0);  // block-uniform
   }
 #ifdef EVE_PP_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -757,6 +787,35 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
+__global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  pp_tile<A_COL, B_COL, EPI, ACT, WGRAD, BIAS_GRAD, BKI, WR>(pr, smem);
+#endif
+}
+
+// Weight gradients.  The bias gradient (column sums of the k-major A tile) is taken by the tiles of the FIRST
+// column tile only; with 64-deep sub-tiles its accumulators do not fit next to 96 fragment and 128 accumulator
+// registers, so those tiles run the 32-deep body and all others the 64-deep one without bias sums (a K step of
+// 32 has half the MFMA work per barrier pair and reaches about half the MFMA rate).  Block-uniform branch.
+template <int EPI>
+__global__ __launch_bounds__(512) void grouped_gemm_pp_wgrad(MfmaPair pr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool second = blockIdx.x >= (unsigned)pr.n0;
+  const MfmaDesc& d = pr.d[second ? 1 : 0];
+  const unsigned bid = second ? blockIdx.x - (unsigned)pr.n0 : blockIdx.x;
+  const int tiles_m = (d.Mext + 255) / 256, tiles_per_group = tiles_m * (d.N / BN);
+  const int ngroups = d.E_local * max(d.ksplit, 1);
+  const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
+  const int local = bid >> 3, item = (bid & 7) * per_xcd + local;
+  if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
+  const bool first_col_tile = (item % tiles_per_group) / tiles_m == 0;
+  if (first_col_tile) pp_tile<true, true, EPI, EVE_ACT_IDENTITY, true, true, 32, 4>(pr, smem);
+  else pp_tile<true, true, EPI, EVE_ACT_IDENTITY, true, false, 64, 4>(pr, smem);
+#endif
+}
 
 // ------------------------------------------------------------------ persistent ping-pong kernel
 // The schedule of grouped_gemm_pp, but a workgroup walks tiles gb = blockIdx.x, + gridDim.x, ... and the
@@ -847,12 +906,11 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 64 * WR, KI = BKI / 16, NSLOT = 5;
   static_assert(WR == 4 || (WR == 3 && !A_COL && !WGRAD), "192-row tiles: row-major A only");
-  static_assert(!BIAS_GRAD || (A_COL && BKI == 32 && WR == 4), "bias gradient: 32-deep k-major A tiles");
+  static_assert(!BIAS_GRAD || (A_COL && WR == 4), "bias gradient: k-major A tiles");
   constexpr int kSub = 256 * BKI * 2;
   constexpr int kRing = NSLOT * kSub;
   constexpr int kStageWave = 16 * EPI_LD * 4;
   constexpr bool kStageInRing = kRing + 8 * kStageWave > 160 * 1024;
-  static_assert(!kStageInRing || !WGRAD, "a tile without K steps (weight gradients only) needs per-wave images");
   constexpr int NPB = kSub / 1024 / 4;
   constexpr int NPA = BM * BKI * 2 / 1024 / 4;
   constexpr int NP = NPB;
@@ -1030,8 +1088,21 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
     // received no rows -- waves 0-3 are in their next E phase while waves 4-7 are still in this one)
     float* ep = reinterpret_cast<float*>(kStageInRing ? smem + wrap(sl_c + 4) * kSub + w4 * kStageWave
                                                       : smem + kRing + wave_u * kStageWave);
-    tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0, cur.n0, cur.mext,
-                                     wave, lane);
+    if (WGRAD && cur.nk == 0) {
+      // An expert that received no rows: its gradient tile is zero.  Stored straight from registers -- after
+      // such a tile waves 0-3 reach their next E phase while waves 4-7 are still in this one, and with the
+      // staging image inside the ring the two would share it.
+      bf16_t* Cg = d.C + (size_t)cur.z * d.c_g;
+#pragma unroll 4
+      for (int it = 0; it < WR * 4; ++it) {
+        const int m = cur.m0 + wm * (WR * 32) + it * 8 + (lane >> 3);
+        if (m < cur.mext)
+          *reinterpret_cast<uint4*>(Cg + (size_t)m * d.ldc + cur.n0 + wn * 64 + (lane & 7) * 8) = make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0, cur.n0, cur.mext,
+                                       wave, lane);
+    }
     if constexpr (BIAS_GRAD) {
       if (do_bias_grad) {
 #pragma unroll
@@ -1067,6 +1138,23 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+
+// out[i] = bf16(sum over splits j of part[j * stride + i]), splits in order; 8 elements per thread
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, bf16_t* __restrict__ out,
+                                                           size_t n, size_t stride, int nsplit) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = 0.f;
+  for (int j = 0; j < nsplit; ++j) {
+    const float4 a = *reinterpret_cast<const float4*>(part + (size_t)j * stride + i);
+    const float4 b = *reinterpret_cast<const float4*>(part + (size_t)j * stride + i + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  *reinterpret_cast<uint4*>(out + i) = pack8(v);
+}
 
 bool ffn_mfma_supported(int M, int I) { return M % 256 == 0 && I % 256 == 0; }
 
@@ -1134,7 +1222,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   constexpr int kEpi = 8 * 32 * EPI_LD * 4;
   constexpr int kLds = 5 * 256 * BKI * 2 > kEpi ? 5 * 256 * BKI * 2 : kEpi;
   auto blocks = [](const MfmaDesc& q) {
-    const int ngroups = WGRAD ? q.E_local : q.G;
+    const int ngroups = WGRAD ? q.E_local * (q.ksplit > 1 ? q.ksplit : 1) : q.G;
     return 8 * ceil_div(ngroups * (q.N / BN) * ceil_div(q.Mext, 64 * WR), 8);
   };
   MfmaPair pr;
@@ -1145,8 +1233,8 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   // persistent variant: one workgroup per CU walks the tiles (single K segment only)
   // (not for the activation epilogues: their E phases are long and VALU-heavy, and run one half after the
   // other here, where the one-tile kernel overlaps the two halves' epilogues -- measured 4-6 % slower)
-  const bool persist = use_persistent() && EPI != MEPI_BIAS_ACT && EPI != MEPI_DACT && (!WGRAD || d.G == d.E_local) &&
-                       pr.ntotal > cu_count();
+  const bool persist = use_persistent() && EPI != MEPI_BIAS_ACT && EPI != MEPI_DACT && EPI != MEPI_STORE_F32 &&
+                       (!WGRAD || d.G == d.E_local) && pr.ntotal > cu_count();
   constexpr int kStage = 8 * 16 * EPI_LD * 4;
   constexpr int kLdsP = (5 * 256 * BKI * 2 + kStage > 160 * 1024) ? 5 * 256 * BKI * 2 : 5 * 256 * BKI * 2 + kStage;
   dim3 grid(persist ? (cu_count() / 8) * 8 : pr.ntotal);
@@ -1230,9 +1318,56 @@ int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, 
   return launch<false, false, MEPI_BIAS, false, false>(d, act, st);
 }
 
+// both weight-gradient GEMMs of a backward pass in one launch of grouped_gemm_pp_wgrad
+template <int EPI>
+static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st) {
+  constexpr int kLds = 5 * 256 * 64 * 2;
+  auto blocks = [](const MfmaDesc& q) {
+    return 8 * ceil_div(q.E_local * (q.ksplit > 1 ? q.ksplit : 1) * (q.N / BN) * ceil_div(q.Mext, 256), 8);
+  };
+  MfmaPair pr;
+  pr.d[0] = d;
+  pr.d[1] = d2;
+  pr.n0 = blocks(d);
+  pr.ntotal = pr.n0 + blocks(d2);
+  auto kern = grouped_gemm_pp_wgrad<EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) {
+      set_error("ffn_mfma: cannot reserve %d bytes of LDS", kLds);
+      return EVE_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pr.ntotal), dim3(512), kLds, st, pr);
+  EVE_CHECK_LAUNCH("grouped_gemm_pp_wgrad");
+  return EVE_OK;
+}
+
+// Weight-gradient split-K factor: with few local experts (expert parallelism, the two-group modality split) the
+// two dW GEMMs have too few 256 x 256 tiles for the CUs, each with a very long K loop; the K range is then cut
+// into `ksplit` slices (whole segments first, then row slices) with fp32 partials and a reduction pass.
+static int wgrad_ksplit(int G, int E_local, int M, int I) {
+  const long tiles = 2L * E_local * (M / 256) * (I / 256);  // both GEMMs share a launch
+  const long cus = cu_count();
+  if (getenv("EVE_FFN_KSPLIT")) return max(1, atoi(getenv("EVE_FFN_KSPLIT")));  // debug knob
+  if (tiles >= 2 * cus) return 1;
+  int j = 1;
+  while (j < 8 && tiles * j < 4 * cus) j *= 2;
+  const int nseg = G / E_local;
+  if ((nseg & (nseg - 1)) != 0) return j <= nseg && nseg % j == 0 ? j : 1;  // odd segment counts: whole-segment splits only
+  return j;
+}
+
+size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int M, int I) {
+  const int j = wgrad_ksplit(G, E_local, M, I);
+  if (j <= 1) return 0;
+  return (size_t)j * E_local * (2 * (size_t)M * I + M + I) * sizeof(float);
+}
+
 int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2, void* dz,
                  void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G, int E_local, int R,
-                 int M, int I, int act, hipStream_t st) {
+                 int M, int I, int act, void* workspace, size_t workspace_bytes, hipStream_t st) {
   MfmaDesc d{};
   d.G = G; d.E_local = E_local; d.rows = rows;
   // dz = (dy @ w2) * act'(z): A = dy [R,M] row-major, B = w2 [M,I] k-major
@@ -1257,7 +1392,36 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   d1.A = (const bf16_t*)dz; d1.a_g = (long)R * I; d1.lda = I;
   d1.B = (const bf16_t*)x; d1.b_g = (long)R * M; d1.ldb = M;
   d1.C = (bf16_t*)dw1; d1.c_g = (long)I * M; d1.ldc = M; d1.N = M; d1.K = R; d1.dbias = (bf16_t*)db1;
-  if (use_pingpong()) return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, &d1);  // one launch for both
+  if (use_pingpong()) {
+    const int ks = wgrad_ksplit(G, E_local, M, I);
+    if (ks > 1) {
+      const size_t need = ffn_bwd_mfma_workspace_bytes(G, E_local, M, I);
+      if (!workspace || workspace_bytes < need) {
+        set_error("eve_ffn_bwd: workspace %zu < %zu (eve_ffn_bwd_workspace_bytes)", workspace_bytes, need);
+        return EVE_ERR_WORKSPACE;
+      }
+      const size_t nw = (size_t)E_local * M * I;
+      float* ws = static_cast<float*>(workspace);
+      float* p_dw2 = ws;                       // [ks][E_local][M][I]
+      float* p_dw1 = p_dw2 + ks * nw;          // [ks][E_local][I][M]
+      float* p_db2 = p_dw1 + ks * nw;          // [ks][E_local][M]
+      float* p_db1 = p_db2 + (size_t)ks * E_local * M;  // [ks][E_local][I]
+      d.ksplit = ks; d.Cpart = p_dw2; d.dbias_part = p_db2;
+      d1.ksplit = ks; d1.Cpart = p_dw1; d1.dbias_part = p_db1;
+      if (int rc = launch_pp_wgrad<MEPI_STORE_F32>(d, d1, st)) return rc;
+      auto reduce = [&](const float* part, void* out, size_t n) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, part, (bf16_t*)out, n, n, ks);
+      };
+      reduce(p_dw2, dw2, nw);
+      reduce(p_dw1, dw1, nw);
+      reduce(p_db2, db2, (size_t)E_local * M);
+      reduce(p_db1, db1, (size_t)E_local * I);
+      EVE_CHECK_LAUNCH("wgrad_reduce_kernel");
+      return EVE_OK;
+    }
+    if (!getenv("EVE_FFN_WGRAD32")) return launch_pp_wgrad<MEPI_STORE>(d, d1, st);  // one launch for both GEMMs
+    return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, &d1);  // debug knob: all tiles 32 deep (persistent)
+  }
   if (int rc = launch<true, true, MEPI_STORE, true, true>(d, act, st)) return rc;
   return launch<true, true, MEPI_STORE, true, true>(d1, act, st);
 }

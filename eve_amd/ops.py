@@ -261,8 +261,10 @@ def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int):
     db1 = torch.empty(E_l, I, dtype=x.dtype, device=dev)
     dw2 = torch.empty(E_l, M, I, dtype=x.dtype, device=dev)
     db2 = torch.empty(E_l, M, dtype=x.dtype, device=dev)
+    nbytes = _lib.load().eve_ffn_bwd_workspace_bytes(G, E_l, R, M, I, _dt(x))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     PROFILE.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),
-              _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _stream())
+              _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _p(ws), nbytes, _stream())
     return dx, dw1, db1, dw2, db2
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 1
+#define EVE_MOE_ABI_VERSION 2
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -173,7 +173,13 @@ int eve_ffn_fwd(const void* x, const void* w1, const void* b1, const void* w2, c
  * Rows >= rows[g] contribute nothing and their dx/dz rows are left untouched. */
 int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2,
                 void* dz, void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G,
-                int E_local, int R, int M, int I, int act, int dtype, void* stream);
+                int E_local, int R, int M, int I, int act, int dtype, void* workspace, size_t workspace_bytes,
+                void* stream);
+
+/* Scratch for eve_ffn_bwd (256-byte aligned device memory, contents irrelevant): non-zero only when the two
+ * weight-gradient GEMMs are split along K -- few local experts (expert parallelism, the two-group modality
+ * split) leave too few output tiles for the CUs; the slices' fp32 partials are then summed in a fixed order. */
+size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype);
 
 /* ------------------------------------------------- hard modality split of the non-MoE layers
  * Reference models/multiway_transformer.py:366-370: vision positions [:, :n_vis] go through
