@@ -135,7 +135,9 @@ def main():
     if use_graph:
         import eve_amd
         graphed = eve_amd.GraphedTrainStep(moe, h, dout, mode="vl")
-        step = lambda: graphed(h, dout)
+        # h / dout are resident in the graph's input buffers (graphed.static_h / static_dout), as when the
+        # producing layer writes them in place; the eager path reads them in place as well
+        step = lambda: graphed()
     else:
         step = eager_step
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("EVE_MOE_LIB", LIB_PATH)  # A/B experiments: an altern
 F32, BF16 = 0, 1
 MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3
 ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P, _I, _Z = c_void_p, c_int, c_size_t
 
@@ -28,7 +28,7 @@ SIGNATURES = {
     "eve_capacity": (c_int, [_I, _I, c_double, _I]),
     "eve_gate_logits_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eve_gate_workspace_bytes": (c_size_t, [_I, _I]),
-    "eve_gate_top2_fwd": (c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "eve_gate_top2_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "eve_gumbel_from_uniform": (c_int, [_P, _P, c_long, _P]),
     "eve_gate_top2_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "eve_gate_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),
@@ -37,7 +37,7 @@ SIGNATURES = {
     "eve_dispatch_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eve_embed_grad_workspace_bytes": (c_size_t, [_I, _I]),
     "eve_embed_grad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "eve_route_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "eve_route_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "eve_combine_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "eve_combine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eve_split_ln_fwd": (c_int, [_P] * 8 + [_I] * 5 + [c_float, _I, _P]),

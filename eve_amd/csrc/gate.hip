@@ -73,6 +73,18 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const T* __restrict__ 
 }
 
 // ===================================================================== top-2 gating
+// Gumbel(0,1) variate of one standard-uniform draw with torch.distributions.Gumbel's arithmetic
+// (sharded_moe.py:70-77,:186): u = tiny + r * ((1 - eps) - tiny), then 0 + (-1) * log(0 + (-1) * log(u)),
+// every step rounded to fp32, no contraction.
+__device__ __forceinline__ float gumbel_of_uniform(float r) {
+  const float low = 1.17549435e-38f;                 // finfo(float32).tiny
+  const float high = 1.0f - 1.1920928955078125e-07f;  // 1 - finfo(float32).eps
+  const float span = __fsub_rn(high, low);
+  const float u = __fadd_rn(low, __fmul_rn(r, span));
+  const float a = __fadd_rn(0.f, __fmul_rn(-1.f, logf(u)));
+  return __fadd_rn(0.f, __fmul_rn(-1.f, logf(a)));
+}
+
 // Pass 1 (select): one thread per token.  softmax, first / second choice, rank of the token
 // among earlier tokens OF ITS BLOCK with the same choice (wave ballots + LDS), per-block
 // histograms and per-block column sums of the gates.  Also clears slot_token.
@@ -83,15 +95,19 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const T* __restrict__ 
 //   gsum   [E][nblk]      float, per-block column sums of gates
 //   tot    [2][E]         totals
 __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
-    const float* __restrict__ logits, const float* __restrict__ noise, int S, int E, float* __restrict__ gates,
-    int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank, float* __restrict__ gsum,
-    int32_t* __restrict__ slot_token, int num_slots, int use_tile) {
+    const float* __restrict__ logits, const float* __restrict__ noise, int noise_is_uniform, int S, int E,
+    float* __restrict__ gates, int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank,
+    float* __restrict__ gsum, int32_t* __restrict__ slot_token, float* __restrict__ slot_weight, int num_slots,
+    int use_tile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(kGateBlock == 64, "one wave per block");
   float* tile = reinterpret_cast<float*>(smem);  // [64][E+1] gates of the block's tokens (use_tile)
 
   // clear the inverse map (consumed by pass 3, which runs after this kernel completes)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_slots; i += gridDim.x * blockDim.x) slot_token[i] = -1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_slots; i += gridDim.x * blockDim.x) {
+    slot_token[i] = -1;
+    slot_weight[i] = 0.f;
+  }
 
   const int s = blockIdx.x * kGateBlock + threadIdx.x;
   const bool live = s < S;
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
   float best2 = -INFINITY;
   for (int e = 0; e < E; ++e) {
     if (e == i1) continue;
-    const float v = row[e] + nrow[e];
+    const float v = row[e] + (noise_is_uniform ? gumbel_of_uniform(nrow[e]) : nrow[e]);
     if (i2 < 0 || v > best2) { best2 = v; i2 = e; }
   }
   if (i2 < 0) i2 = 0;  // E == 1: masked_fill leaves all -inf, argmax -> 0
@@ -158,64 +174,135 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
   }
 }
 
-// Pass 1 for E <= 32: 256 threads per 64-token block.  Part A works with one lane per (token, expert)
-// -- a wave handles two tokens at a time, its 32-lane halves reduce max / sum / arg-max with butterflies
-// -- so that logits, noise and gates move as coalesced 128-byte rows; part B is the ballot ranking of
-// the kernel above with the experts split over the four waves.  Same outputs, same workspace layout.
-__device__ __forceinline__ void argmax_step(float& v, int& i, int off) {
-  const float ov = __shfl_xor(v, off, 64);
-  const int oi = __shfl_xor(i, off, 64);
+// value of lane (l ^ 1) / (l ^ 2): quad-permute DPP moves, no LDS crossbar trip
+template <int CTRL>
+__device__ __forceinline__ float quad_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int quad_i(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;
+template <int CTRL>
+__device__ __forceinline__ void argmax_quad(float& v, int& i) {
+  const float ov = quad_f<CTRL>(v);
+  const int oi = quad_i<CTRL>(i);
   if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
+// Pass 1 for E <= 32: 256 threads per 64-token block, FOUR lanes per token, each owning eight consecutive
+// experts in registers (two 16-byte loads per operand when E == 32, so a wave reads 2 KiB contiguous
+// rows): max / sum / arg-max are seven in-register steps plus two quad-permute DPP steps.  `noise` holds
+// Gumbel variates, or (noise_is_uniform) the standard-uniform draws they are made of, transformed here.
+// Part B is the ballot ranking of the kernel above with the experts split over the four waves.  Same
+// outputs and workspace layout; also clears slot_token / slot_weight for pass 3.
+template <bool E32>
 __global__ __launch_bounds__(256) void gate_select32_kernel(
-    const float* __restrict__ logits, const float* __restrict__ noise, int S, int E, float* __restrict__ gates,
-    int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank, float* __restrict__ gsum,
-    int32_t* __restrict__ slot_token, int num_slots) {
+    const float* __restrict__ logits, const float* __restrict__ noise, int noise_is_uniform, int S, int E,
+    float* __restrict__ gates, int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank,
+    float* __restrict__ gsum, int32_t* __restrict__ slot_token, float* __restrict__ slot_weight, int num_slots) {
   __shared__ int ci1[kGateBlock], ci2[kGateBlock];
-  __shared__ float gpart[4][32];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_slots; i += gridDim.x * blockDim.x) slot_token[i] = -1;
+  __shared__ float tile[kGateBlock][33];
+  __shared__ float gpart[8][32];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_slots; i += gridDim.x * blockDim.x) {
+    slot_token[i] = -1;
+    slot_weight[i] = 0.f;
+  }
 
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const int e = lane & 31, tk = lane >> 5;
-  const int ec = min(e, E - 1);
-  float gacc = 0.f;
-#pragma unroll 4
-  for (int it = 0; it < kGateBlock / 8; ++it) {
-    const int t = wave * (kGateBlock / 4) + 2 * it + tk;  // token inside the block
+  {
+    const int q = lane & 3, t = wave * 16 + (lane >> 2);  // token inside the block
     const int s = blockIdx.x * kGateBlock + t;
-    const bool live = s < S, valid = live && e < E;
-    const size_t o = (size_t)(live ? s : 0) * E + ec;
-    const float x = logits[o], nz = noise[o];
-    float mx = valid ? x : -INFINITY;
+    const bool live = s < S;
+    const int e0 = q * 8;
+    float x[8], nz[8];
+    if (E32) {
+      const float4* lp = reinterpret_cast<const float4*>(logits + (size_t)(live ? s : 0) * 32 + e0);
+      const float4* np = reinterpret_cast<const float4*>(noise + (size_t)(live ? s : 0) * 32 + e0);
+      const float4 a = lp[0], b = lp[1], c = np[0], d = np[1];
+      x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
+      nz[0] = c.x, nz[1] = c.y, nz[2] = c.z, nz[3] = c.w, nz[4] = d.x, nz[5] = d.y, nz[6] = d.z, nz[7] = d.w;
+    } else {
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    const float ex = valid ? expf(x - mx) : 0.f;
-    float sum = ex;
+      for (int j = 0; j < 8; ++j) {
+        const size_t o = (size_t)(live ? s : 0) * E + min(e0 + j, E - 1);
+        x[j] = logits[o];
+        nz[j] = noise[o];
+      }
+    }
+    bool valid[8];
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    const float g = ex / sum;
-    if (valid) gates[o] = g;
-    gacc += valid ? g : 0.f;
-    float v1 = valid ? g : -INFINITY;
-    int i1 = e;
+    for (int j = 0; j < 8; ++j) valid[j] = live && (E32 || e0 + j < E);
+    // softmax exactly as exp(x - max) / sum
+    float mx = -INFINITY;
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) argmax_step(v1, i1, off);
-    float v2 = (valid && e != i1) ? x + nz : -INFINITY;
-    int i2 = e;
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, valid[j] ? x[j] : -INFINITY);
+    mx = fmaxf(mx, quad_f<kQuadXor1>(mx));
+    mx = fmaxf(mx, quad_f<kQuadXor2>(mx));
+    float ex[8];
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) argmax_step(v2, i2, off);
-    if (e == 0) {
+    for (int j = 0; j < 8; ++j) ex[j] = valid[j] ? expf(x[j] - mx) : 0.f;
+    float sum = ((ex[0] + ex[4]) + (ex[2] + ex[6])) + ((ex[1] + ex[5]) + (ex[3] + ex[7]));
+    sum += quad_f<kQuadXor1>(sum);
+    sum += quad_f<kQuadXor2>(sum);
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = ex[j] / sum;
+    if (E32) {
+      if (live) {
+        float4* gp = reinterpret_cast<float4*>(gates + (size_t)s * 32 + e0);
+        gp[0] = make_float4(g[0], g[1], g[2], g[3]);
+        gp[1] = make_float4(g[4], g[5], g[6], g[7]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (valid[j]) gates[(size_t)s * E + e0 + j] = g[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[t][e0 + j] = valid[j] ? g[j] : 0.f;
+    // first choice = argmax of the GATES (ties -> lowest e)
+    float v1 = -INFINITY;
+    int i1 = e0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = valid[j] ? g[j] : -INFINITY;
+      if (v > v1) { v1 = v; i1 = e0 + j; }
+    }
+    argmax_quad<kQuadXor1>(v1, i1);
+    argmax_quad<kQuadXor2>(v1, i1);
+    // second choice = argmax of logits + noise with the first choice masked out
+    float v2 = -INFINITY;
+    int i2 = e0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float n = noise_is_uniform ? gumbel_of_uniform(nz[j]) : nz[j];
+      const float v = (valid[j] && e0 + j != i1) ? x[j] + n : -INFINITY;
+      if (v > v2) { v2 = v; i2 = e0 + j; }
+    }
+    argmax_quad<kQuadXor1>(v2, i2);
+    argmax_quad<kQuadXor2>(v2, i2);
+    if (q == 0) {
       ci1[t] = live ? i1 : -1;
       ci2[t] = live ? i2 : -1;  // E == 1: every candidate is -inf and the tie goes to expert 0, as torch.argmax
     }
   }
-  gacc += __shfl_xor(gacc, 32, 64);
-  if (lane < 32) gpart[wave][lane] = gacc;
   __syncthreads();
-  if (threadIdx.x < E)
-    gsum[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-        ((gpart[0][threadIdx.x] + gpart[1][threadIdx.x]) + gpart[2][threadIdx.x]) + gpart[3][threadIdx.x];
+  {  // per-block column sums of the gates (for l_aux), fixed order: 8 rows per thread, then 8 partials
+    const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    float p = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) p += tile[rg * 8 + r][e];
+    gpart[rg][e] = p;
+  }
+  __syncthreads();
+  if (threadIdx.x < E) {
+    float p = gpart[0][threadIdx.x];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) p += gpart[r][threadIdx.x];
+    gsum[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = p;
+  }
 
   // part B: lane = token
   const int s = blockIdx.x * kGateBlock + lane;
@@ -252,6 +339,20 @@ __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restri
   // lane writes its four exclusive prefixes with one 16-byte store.  nblk is padded to a multiple of 4
   // in the workspace layout, so the vector accesses stay inside the row.
   constexpr int R = 4;  // rows whose loads are in flight together
+  // column sums of the gates: wave w owns experts w, w + nw, ...; their loads are issued first so that they
+  // are in flight together with the histogram loads below (one memory round trip instead of two)
+  constexpr int GE = 2, GB = 4;  // experts per wave and 64-block strides held in registers
+  float greg[GE][GB];
+  const bool g_in_regs = E <= GE * nw && nblk <= GB * 64;
+  if (g_in_regs) {
+#pragma unroll
+    for (int i = 0; i < GE; ++i)
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        const int e = wave + i * nw, b = lane + 64 * k;
+        greg[i][k] = (e < E && b < nblk) ? gsum[(size_t)e * nblk + b] : 0.f;
+      }
+  }
   for (int pair0 = wave; pair0 < 2 * E; pair0 += R * nw) {
     int carry[R];
 #pragma unroll
@@ -290,11 +391,22 @@ __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restri
     for (int r = 0; r < R; ++r)
       if (lane == 0 && pair0 + r * nw < 2 * E) stot[pair0 + r * nw] = carry[r];
   }
-  for (int e = wave; e < E; e += nw) {  // fixed lane-strided order, then butterfly: deterministic
-    float g = 0.f;
-    for (int b = lane; b < nblk; b += 64) g += gsum[(size_t)e * nblk + b];
-    g = wave_sum(g);
-    if (lane == 0) sme[e] = g;
+  if (g_in_regs) {  // fixed lane-strided order, then butterfly: deterministic
+#pragma unroll
+    for (int i = 0; i < GE; ++i) {
+      float g = 0.f;
+#pragma unroll
+      for (int k = 0; k < GB; ++k) g += greg[i][k];
+      g = wave_sum(g);
+      if (lane == 0 && wave + i * nw < E) sme[wave + i * nw] = g;
+    }
+  } else {
+    for (int e = wave; e < E; e += nw) {
+      float g = 0.f;
+      for (int b = lane; b < nblk; b += 64) g += gsum[(size_t)e * nblk + b];
+      g = wave_sum(g);
+      if (lane == 0) sme[e] = g;
+    }
   }
   __syncthreads();
   for (int t = threadIdx.x; t < 2 * E; t += blockDim.x) tot[t] = stot[t];
@@ -303,14 +415,18 @@ __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restri
     const int filled = stot[e] + stot[E + e];
     rows[e] = filled < C ? filled : C;
   }
+  // l_aux = mean_e(mean_s gates * mean_s mask1) * E * E     (sharded_moe.py:202-204): the products in
+  // parallel, their sum by one thread in expert order
+  float* term = sme + E;  // [E]
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    const float me = sme[e] / (float)S;
+    const float ce = (float)stot[e] / (float)S;
+    term[e] = me * ce;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    // l_aux = mean_e(mean_s gates * mean_s mask1) * E * E     (sharded_moe.py:202-204)
     float acc = 0.f;
-    for (int e = 0; e < E; ++e) {
-      const float me = sme[e] / (float)S;
-      const float ce = (float)stot[e] / (float)S;
-      acc += me * ce;
-    }
+    for (int e = 0; e < E; ++e) acc += term[e];
     l_aux[0] = acc / (float)E * (float)E * (float)E;
   }
 }
@@ -516,6 +632,34 @@ __device__ __forceinline__ float x_elem(const T* __restrict__ hp, const T* __res
 // (deterministic).  Lane (i = lane & 31, hh = lane >> 5) supplies, for each 16-wide k block, the 8
 // contiguous elements k0 + 8*hh .. +8 of token i (A) and of expert i (B): MFMA step j multiplies
 // k0+j and k0+8+j.
+// Exact three-way split of eight fp32 values into bf16 parts, w = hi + mid + lo with every part the
+// TRUNCATED top 8 significant bits of what is left (24 = 8 + 8 + 8, the subtractions are exact): a bf16
+// MFMA over (x, hi), (x, mid), (x, lo) with bf16 x then forms the same exact products as an fp32 FMA and
+// accumulates them in fp32, at 3 x 32 issue cycles per 16 k instead of 8 x 64 for v_mfma_f32_32x32x2_f32.
+typedef __attribute__((ext_vector_type(8))) __bf16 gate_bf16x8;
+__device__ __forceinline__ void split3_bf16(const float (&w)[8], gate_bf16x8& hi, gate_bf16x8& mid, gate_bf16x8& lo) {
+  uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    uint32_t h[2], m[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float x = w[2 * p + q];
+      h[q] = __float_as_uint(x) & 0xffff0000u;
+      const float r = x - __uint_as_float(h[q]);
+      m[q] = __float_as_uint(r) & 0xffff0000u;
+      const float r2 = r - __uint_as_float(m[q]);
+      l[q] = __float_as_uint(r2);  // at most 8 significant bits left: exact in bf16
+    }
+    ph[p] = (h[0] >> 16) | h[1];
+    pm[p] = (m[0] >> 16) | m[1];
+    pl[p] = (l[0] >> 16) | (l[1] & 0xffff0000u);
+  }
+  hi = __builtin_bit_cast(gate_bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+  mid = __builtin_bit_cast(gate_bf16x8, make_uint4(pm[0], pm[1], pm[2], pm[3]));
+  lo = __builtin_bit_cast(gate_bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+}
+
 template <typename T, bool EMB>
 __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
                                                                const T* __restrict__ temb,
@@ -539,21 +683,43 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   constexpr int KU = 4;  // 16-wide k blocks whose loads are issued together (latency hiding)
-  for (int k0 = k_lo; k0 < k_hi; k0 += 16 * KU) {
-    float a[KU][8], b[KU][8];
+  if constexpr (Vec16<T>::N == 8) {
+    // bf16 activations: x = bf16(h + embed) is a bf16 MFMA operand as it is; wg goes in as its exact
+    // three-way bf16 split (see split3_bf16)
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16 * KU) {
+      Vec16<T> xa[KU];
+      float b[KU][8];
 #pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const int k = min(k0 + 16 * u, M - 16) + 8 * hh;  // clamp: blocks past the range are masked below
-      const Vec16<T> hv0 = load16<T>(hp + k);
-      if constexpr (Vec16<T>::N == 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[u][j] = hv0.get(j);
+      for (int u = 0; u < KU; ++u) {
+        const int k = min(k0 + 16 * u, M - 16) + 8 * hh;  // clamp: blocks past the range are masked below
+        xa[u] = load16<T>(hp + k);
         if constexpr (EMB) {
           const Vec16<T> ev = load16<T>(emb + k);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) a[u][j] = to_f32<T>(from_f32<T>(a[u][j] + ev.get(j)));
+          for (int j = 0; j < 8; ++j) xa[u].set(j, xa[u].get(j) + ev.get(j));
         }
-      } else {
+        const float m = (k0 + 16 * u < k_hi) ? wmask : 0.f;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp + k), w1 = *reinterpret_cast<const float4*>(wp + k + 4);
+        b[u][0] = w0.x * m; b[u][1] = w0.y * m; b[u][2] = w0.z * m; b[u][3] = w0.w * m;
+        b[u][4] = w1.x * m; b[u][5] = w1.y * m; b[u][6] = w1.z * m; b[u][7] = w1.w * m;
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        gate_bf16x8 bh, bm, bl;
+        split3_bf16(b[u], bh, bm, bl);
+        const gate_bf16x8 av = __builtin_bit_cast(gate_bf16x8, xa[u].raw);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc, 0, 0, 0);
+      }
+    }
+  } else {
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16 * KU) {
+      float a[KU][8], b[KU][8];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int k = min(k0 + 16 * u, M - 16) + 8 * hh;  // clamp: blocks past the range are masked below
+        const Vec16<T> hv0 = load16<T>(hp + k);
         const Vec16<T> hv1 = load16<T>(hp + k + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a[u][j] = hv0.get(j); a[u][4 + j] = hv1.get(j); }
@@ -562,16 +728,16 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
 #pragma unroll
           for (int j = 0; j < 4; ++j) { a[u][j] += e0.get(j); a[u][4 + j] += e1.get(j); }
         }
+        const float m = (k0 + 16 * u < k_hi) ? wmask : 0.f;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp + k), w1 = *reinterpret_cast<const float4*>(wp + k + 4);
+        b[u][0] = w0.x * m; b[u][1] = w0.y * m; b[u][2] = w0.z * m; b[u][3] = w0.w * m;
+        b[u][4] = w1.x * m; b[u][5] = w1.y * m; b[u][6] = w1.z * m; b[u][7] = w1.w * m;
       }
-      const float m = (k0 + 16 * u < k_hi) ? wmask : 0.f;
-      const float4 w0 = *reinterpret_cast<const float4*>(wp + k), w1 = *reinterpret_cast<const float4*>(wp + k + 4);
-      b[u][0] = w0.x * m; b[u][1] = w0.y * m; b[u][2] = w0.z * m; b[u][3] = w0.w * m;
-      b[u][4] = w1.x * m; b[u][5] = w1.y * m; b[u][6] = w1.z * m; b[u][7] = w1.w * m;
+#pragma unroll
+      for (int u = 0; u < KU; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < KU; ++u)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -695,6 +861,93 @@ __global__ __launch_bounds__(256, 2) void gate_wgrad_mfma_kernel(const T* __rest
   }
 }
 
+// bf16 activations: dwg partials on v_mfma_f32_32x32x16_bf16, 16 tokens per instruction.  x = bf16(h + embed)
+// is an exact bf16 operand and dlogits goes in as its exact three-way bf16 split (split3_bf16), so the
+// products are those of an fp32 FMA.  Block = TS tokens x 256 columns; the four waves split the COLUMNS
+// (64 each: two MFMA tiles, lane i owns columns 2i and 2i+1 of its wave's slab), so no cross-wave
+// reduction and 32 accumulator registers; a lane loads one dword per token row -- a half-wave reads 128
+// contiguous bytes of a row -- and the B operand of tile t is half t of the 8 rows' dwords.
+template <bool EMB>
+__global__ __launch_bounds__(256, 2) void gate_wgrad_bf16_kernel(const bf16_t* __restrict__ h,
+                                                              const bf16_t* __restrict__ vemb,
+                                                              const bf16_t* __restrict__ temb,
+                                                              const float* __restrict__ dlogits,
+                                                              float* __restrict__ part, int S, int T_, int n_vis,
+                                                              int mode, int M, int E, int TS) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int i = lane & 31, hh = lane >> 5;
+  const int col0 = blockIdx.y * 256 + wave * 64 + 2 * i;
+  const bool col_ok = col0 < M;        // M % 8 == 0: a column pair is inside or outside as a whole
+  const int colc = col_ok ? col0 : 0;  // lanes past the last column load column 0 and store nothing
+  const int ic = min(i, E - 1);
+  const int s_begin = blockIdx.x * TS, s_end = min(S, s_begin + TS);
+  uint32_t ev_v = 0, ev_t = 0;
+  if constexpr (EMB) {
+    ev_v = *reinterpret_cast<const uint32_t*>(vemb + colc);
+    ev_t = *reinterpret_cast<const uint32_t*>(temb + colc);
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  constexpr int ST = 4;  // 16-token steps whose loads are issued together
+  for (int s16 = s_begin; s16 < s_end; s16 += 16 * ST) {
+    float a[ST][8];
+    uint32_t xv[ST][8];
+#pragma unroll
+    for (int u = 0; u < ST; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // unconditional loads (clamped); dead tokens are masked through a
+        const int sc = min(s16 + 16 * u + 8 * hh + j, S - 1);
+        a[u][j] = dlogits[(size_t)sc * E + ic];
+        xv[u][j] = *reinterpret_cast<const uint32_t*>(h + (size_t)sc * M + colc);
+      }
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int sj0 = s16 + 16 * u + 8 * hh;
+      int pos = 0;
+      if constexpr (EMB) pos = mode == EVE_MODE_VL ? sj0 % T_ : 0;  // position inside the sequence
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[u][j] = (sj0 + j < s_end && i < E) ? a[u][j] : 0.f;
+        if constexpr (EMB) {
+          const bool text = mode == EVE_MODE_TEXT || (mode == EVE_MODE_VL && pos >= n_vis);
+          const uint32_t e = text ? ev_t : ev_v;
+          const float x0 = __uint_as_float(xv[u][j] << 16) + __uint_as_float(e << 16);
+          const float x1 = __uint_as_float(xv[u][j] & 0xffff0000u) + __uint_as_float(e & 0xffff0000u);
+          const uint32_t b0 = (uint32_t)__builtin_bit_cast(unsigned short, static_cast<bf16_t>(x0));
+          const uint32_t b1 = (uint32_t)__builtin_bit_cast(unsigned short, static_cast<bf16_t>(x1));
+          xv[u][j] = b0 | (b1 << 16);
+          pos = pos + 1 == T_ ? 0 : pos + 1;
+        }
+      }
+      gate_bf16x8 ah, am, al;
+      split3_bf16(a[u], ah, am, al);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        uint32_t w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const uint32_t w0 = xv[u][2 * p], w1 = xv[u][2 * p + 1];
+          w[p] = t ? ((w0 >> 16) | (w1 & 0xffff0000u)) : ((w0 & 0xffffu) | (w1 << 16));
+        }
+        const gate_bf16x8 bt = __builtin_bit_cast(gate_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bt, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bt, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bt, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (!col_ok) return;
+  float* out = part + (size_t)blockIdx.x * E * M;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;  // expert
+    if (row < E) *reinterpret_cast<float2*>(out + (size_t)row * M + col0) = make_float2(acc[0][r], acc[1][r]);
+  }
+}
+
 // out[i] = sum over parts of part[p][i], in a fixed order: 4 slices of the parts summed by 4 thread
 // groups, then the slices in order.  Block = 64 outputs x 4 slices.
 __global__ __launch_bounds__(256) void sum_partials4_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -785,14 +1038,8 @@ using namespace eve;
 // then 0 + (-1) * log(0 + (-1) * log(u)), every step rounded to fp32.  This is the same arithmetic, in
 // the same order and without contraction, in one pass.
 __global__ void gumbel_from_uniform_kernel(const float* __restrict__ r, float* __restrict__ out, long n) {
-  const float low = 1.17549435e-38f;                 // finfo(float32).tiny
-  const float high = 1.0f - 1.1920928955078125e-07f;  // 1 - finfo(float32).eps
-  const float span = __fsub_rn(high, low);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float u = __fadd_rn(low, __fmul_rn(r[i], span));
-    const float a = __fadd_rn(0.f, __fmul_rn(-1.f, logf(u)));
-    out[i] = __fadd_rn(0.f, __fmul_rn(-1.f, logf(a)));
-  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = gumbel_of_uniform(r[i]);
 }
 
 extern "C" int eve_gumbel_from_uniform(const float* uniform, float* noise, long n, void* stream) {
@@ -827,7 +1074,7 @@ extern "C" size_t eve_gate_workspace_bytes(int S, int E) {
   return gate_ws_layout(S, E).total;
 }
 
-extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int S, int E, int C, float* gates,
+extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C, float* gates,
                                  int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
                                  float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux,
                                  void* workspace, size_t workspace_bytes, void* stream) {
@@ -848,17 +1095,21 @@ extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int S,
   int32_t* tot = reinterpret_cast<int32_t*>(ws + w.tot);
   hipStream_t st = S_(stream);
   if (E <= 32) {
-    hipLaunchKernelGGL(gate_select32_kernel, dim3(w.nblk), dim3(256), 0, st, logits, noise, S, E, gates, idx, hist, rank,
-                       gsum, slot_token, E * C);
+    if (E == 32)
+      hipLaunchKernelGGL(gate_select32_kernel<true>, dim3(w.nblk), dim3(256), 0, st, logits, noise, noise_is_uniform, S, E,
+                         gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C);
+    else
+      hipLaunchKernelGGL(gate_select32_kernel<false>, dim3(w.nblk), dim3(256), 0, st, logits, noise, noise_is_uniform, S, E,
+                         gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C);
     EVE_CHECK_LAUNCH("gate_select32_kernel");
   } else {
     const int use_tile = E <= 128 ? 1 : 0;
     const size_t lds1 = use_tile ? (size_t)kGateBlock * (E + 1) * 4 : 0;
-    hipLaunchKernelGGL(gate_select_kernel, dim3(w.nblk), dim3(kGateBlock), lds1, st, logits, noise, S, E, gates, idx,
-                       hist, rank, gsum, slot_token, E * C, use_tile);
+    hipLaunchKernelGGL(gate_select_kernel, dim3(w.nblk), dim3(kGateBlock), lds1, st, logits, noise, noise_is_uniform, S, E,
+                       gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C, use_tile);
     EVE_CHECK_LAUNCH("gate_select_kernel");
   }
-  const size_t lds2 = (size_t)3 * E * 4;
+  const size_t lds2 = (size_t)4 * E * 4;
   hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(1024), lds2, st, hist, boff, gsum, tot, exp_counts, rows, l_aux, S,
                      E, C, w.nblk);
   EVE_CHECK_LAUNCH("gate_scan_kernel");
@@ -888,6 +1139,8 @@ extern "C" int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const i
 
 static const int kWgradTS = 64;       // VALU kernel
 static const int kWgradMfmaTS = 96;   // fp32-MFMA kernel: tokens per block (24 per wave)
+static const int kWgradBf16TS = 128;  // bf16-MFMA kernel: tokens per block (eight 16-token steps); >= kWgradMfmaTS,
+                                      // so the workspace sized for the fp32 kernel's partials covers it
 static inline bool wgrad_use_mfma(int M, int E) { return E <= 32 && M % 8 == 0; }
 
 extern "C" size_t eve_gate_wgrad_workspace_bytes(int S, int M, int E) {
@@ -907,16 +1160,20 @@ extern "C" int eve_gate_wgrad(const void* h, const void* vision_embed, const voi
   float* part = static_cast<float*>(workspace);
   hipStream_t st = S_(stream);
   if (wgrad_use_mfma(M, E)) {
-    const int nbm = ceil_div(S, kWgradMfmaTS);
     EVE_REQUIRE(dtype == EVE_F32 || dtype == EVE_BF16, EVE_ERR_ARG, "eve_gate_wgrad: bad dtype %d", dtype);
+    const int nbm = ceil_div(S, dtype == EVE_BF16 ? kWgradBf16TS : kWgradMfmaTS);
     const dim3 grid(nbm, ceil_div(M, 256));
 #define EVE_WG_LAUNCH(TT, EMB)                                                                                    \
   hipLaunchKernelGGL((gate_wgrad_mfma_kernel<TT, EMB>), grid, dim3(256), 0, st, (const TT*)h, (const TT*)vision_embed, \
                      (const TT*)text_embed, dlogits, part, S, T, n_vis, mode, M, E, kWgradMfmaTS)
     if (dtype == EVE_F32) {
       if (mode != EVE_MODE_NONE) EVE_WG_LAUNCH(float, true); else EVE_WG_LAUNCH(float, false);
+    } else if (mode != EVE_MODE_NONE) {
+      hipLaunchKernelGGL(gate_wgrad_bf16_kernel<true>, grid, dim3(256), 0, st, (const bf16_t*)h, (const bf16_t*)vision_embed,
+                         (const bf16_t*)text_embed, dlogits, part, S, T, n_vis, mode, M, E, kWgradBf16TS);
     } else {
-      if (mode != EVE_MODE_NONE) EVE_WG_LAUNCH(bf16_t, true); else EVE_WG_LAUNCH(bf16_t, false);
+      hipLaunchKernelGGL(gate_wgrad_bf16_kernel<false>, grid, dim3(256), 0, st, (const bf16_t*)h, (const bf16_t*)vision_embed,
+                         (const bf16_t*)text_embed, dlogits, part, S, T, n_vis, mode, M, E, kWgradBf16TS);
     }
 #undef EVE_WG_LAUNCH
     EVE_CHECK_LAUNCH("gate_wgrad_mfma_kernel");

@@ -147,66 +147,65 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------ combine bwd
-// (a) per slot: dy[slot] = slot_weight * dout[tok] (0 when empty);
+// One pass over dout: half a wave per token reads its dout row once and, for each of its (up to two)
+// slots, forms d_weight[s,k] = <dout[s], y[slot_k]> and writes dy[slot_k] = slot_weight * dout[s].  Slots
+// that hold no token are then zero-filled (dy is read whole by the expert GEMMs of other ranks, and by the
+// weight-gradient GEMMs up to rows[e]).
 template <typename T>
-__global__ __launch_bounds__(256) void combine_bwd_dy_kernel(const T* __restrict__ dout,
-                                                             const int32_t* __restrict__ slot_token,
-                                                             const float* __restrict__ slot_weight,
-                                                             T* __restrict__ dy, int M, int num_slots) {
+__global__ __launch_bounds__(256) void combine_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                          const int32_t* __restrict__ slot,
+                                                          const int32_t* __restrict__ slot_token,
+                                                          const float* __restrict__ slot_weight, T* __restrict__ dy,
+                                                          float* __restrict__ d_weight, int S, int M, int num_slots) {
   constexpr int N = Vec16<T>::N;
-  const int lane = lane_id();
+  const int lane = lane_id(), l32 = lane & 31, half = lane >> 5;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int chunks = M / N;
-  for (int sl = wave; sl < num_slots; sl += nwaves) {
-    const int tok = slot_token[sl];
-    T* dst = dy + (size_t)sl * M;
-    if (tok < 0) {
-      for (int c = lane; c < chunks; c += 64) store16<T>(dst + c * N, zero16<T>());
-      continue;
-    }
-    const float w = slot_weight[sl];
-    const T* src = dout + (size_t)tok * M;
-    for (int c = lane; c < chunks; c += 64) {
-      Vec16<T> v = load16<T>(src + c * N);
+  for (int s0 = 2 * wave; s0 < S; s0 += 2 * nwaves) {
+    const int s = s0 + half;
+    const bool live = s < S;
+    const int s1 = live ? slot[2 * s] : -1, s2 = live ? slot[2 * s + 1] : -1;
+    const float w1 = s1 >= 0 ? slot_weight[s1] : 0.f, w2 = s2 >= 0 ? slot_weight[s2] : 0.f;
+    const T* drow = dout + (size_t)(live ? s : 0) * M;
+    const T* y1 = y + (size_t)max(s1, 0) * M;
+    const T* y2 = y + (size_t)max(s2, 0) * M;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+    for (int c = l32; c < chunks; c += 32) {
+      const Vec16<T> d = load16<T>(drow + c * N);
+      const Vec16<T> v1 = load16<T>(y1 + c * N);  // unconditional (row 0 when there is no slot): loads stay in flight together
+      const Vec16<T> v2 = load16<T>(y2 + c * N);
+      Vec16<T> o1, o2;
 #pragma unroll
-      for (int j = 0; j < N; ++j) v.set(j, w * v.get(j));
-      store16<T>(dst + c * N, v);
+      for (int j = 0; j < N; ++j) {
+        const float dj = d.get(j);
+        a1 = fmaf(dj, v1.get(j), a1);
+        a2 = fmaf(dj, v2.get(j), a2);
+        o1.set(j, w1 * dj);
+        o2.set(j, w2 * dj);
+      }
+      if (s1 >= 0) store16<T>(dy + (size_t)s1 * M + c * N, o1);
+      if (s2 >= 0) store16<T>(dy + (size_t)s2 * M + c * N, o2);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      a1 += __shfl_xor(a1, o, 64);
+      a2 += __shfl_xor(a2, o, 64);
+    }
+    if (l32 == 0 && live) {
+      d_weight[2 * s] = s1 >= 0 ? a1 : 0.f;
+      d_weight[2 * s + 1] = s2 >= 0 ? a2 : 0.f;
     }
   }
-}
-
-// (b) per token: d_weight[s,k] = <dout[s], y[slot_k]>.
-template <typename T>
-__global__ __launch_bounds__(256) void combine_bwd_dw_kernel(const T* __restrict__ dout, const T* __restrict__ y,
-                                                             const int32_t* __restrict__ slot,
-                                                             float* __restrict__ d_weight, int S, int M) {
-  constexpr int N = Vec16<T>::N;
-  const int lane = lane_id();
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  const int chunks = M / N;
-  for (int s = wave; s < S; s += nwaves) {
-    const int s1 = slot[2 * s], s2 = slot[2 * s + 1];
-    float a1 = 0.f, a2 = 0.f;
-    for (int c = lane; c < chunks; c += 64) {
-      const Vec16<T> d = load16<T>(dout + (size_t)s * M + c * N);
-      if (s1 >= 0) {
-        const Vec16<T> v = load16<T>(y + (size_t)s1 * M + c * N);
-#pragma unroll
-        for (int j = 0; j < N; ++j) a1 = fmaf(d.get(j), v.get(j), a1);
-      }
-      if (s2 >= 0) {
-        const Vec16<T> v = load16<T>(y + (size_t)s2 * M + c * N);
-#pragma unroll
-        for (int j = 0; j < N; ++j) a2 = fmaf(d.get(j), v.get(j), a2);
-      }
-    }
-    a1 = wave_sum(a1);
-    a2 = wave_sum(a2);
-    if (lane == 0) {
-      d_weight[2 * s] = a1;
-      d_weight[2 * s + 1] = a2;
+  for (int base = wave * 64; base < num_slots; base += nwaves * 64) {  // empty slots
+    const int sl = base + lane;
+    unsigned long long empty = __ballot(sl < num_slots && slot_token[min(sl, num_slots - 1)] < 0);
+    while (empty) {
+      const int k = __ffsll((long long)empty) - 1;
+      empty &= empty - 1;
+      T* dst = dy + (size_t)(base + k) * M;
+      for (int c = lane; c < chunks; c += 64) store16<T>(dst + c * N, zero16<T>());
     }
   }
 }
@@ -242,8 +241,9 @@ __global__ __launch_bounds__(128) void embed_grad_partial_kernel(const T* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void embed_grad_final_kernel(const float* __restrict__ part, float* __restrict__ dv,
-                                                               float* __restrict__ dt, int M, int nchunks) {
+template <typename TO>
+__global__ __launch_bounds__(256) void embed_grad_final_kernel(const float* __restrict__ part, TO* __restrict__ dv,
+                                                               TO* __restrict__ dt, int M, int nchunks) {
   __shared__ float red[8][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + tx;   // over 2*M columns: [vision M | text M] per chunk row
@@ -256,16 +256,17 @@ __global__ __launch_bounds__(256) void embed_grad_final_kernel(const float* __re
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) s += red[r][tx];
-    if (col < M) { if (dv) dv[col] = s; }
-    else if (dt) dt[col - M] = s;
+    if (col < M) { if (dv) dv[col] = from_f32<TO>(s); }
+    else if (dt) dt[col - M] = from_f32<TO>(s);
   }
 }
 
 // ------------------------------------------------------- fused routing backward (E <= 32)
 // dh[s] = dxd[slot1] + dxd[slot2] + dlogits[s,:] @ wg, plus the per-block column sums of the ROUNDED dh
 // by modality (the modality-embedding gradients), in one pass over dh.  A block owns 32 tokens:
-//   1. G[32 tokens x M] = dlogits @ wg on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 FMAs),
-//      each wave every fourth 32-column tile, written to LDS;
+//   1. G[32 tokens x M] = dlogits @ wg on the matrix cores (fp32 activations: v_mfma_f32_32x32x2_f32, exact
+//      fp32 FMAs; bf16 activations: both operands split into bf16 hi + lo halves, three bf16 MFMAs),
+//      each wave every eighth 32-column tile, written to LDS;
 //   2. thread per (token, 16-byte column chunk): G + the two gathered dxd rows -> dh, the rounded values
 //      back into G;
 //   3. thread per column: sums of G over the block's vision / text tokens -> part[block][2][M].
@@ -288,14 +289,89 @@ __global__ __launch_bounds__(kRbThreads) void route_bwd_kernel(const T* __restri
   const int s0 = blockIdx.x * kRbTok;
   const int c0 = blockIdx.y * Mb;            // first column of the slab
   const int mb = min(Mb, M - c0);            // columns in it (multiple of N)
-  {  // phase 1
+  __shared__ unsigned text_mask;  // bit t: token s0 + t is a text token
+  __shared__ float dl[kRbTok][33];  // the block's dlogits rows: read coalesced once, not per wave and lane
+  for (int id = threadIdx.x; id < kRbTok * E; id += kRbThreads) {
+    const int t = id / E, e = id - t * E;
+    dl[t][e] = dlogits[(size_t)min(s0 + t, S - 1) * E + e];
+  }
+  if (threadIdx.x < 64) {
+    const bool tx = lane < kRbTok && token_modality(min(s0 + lane, S - 1), T_, n_vis, mode) != 0;
+    const unsigned long long m = __ballot(tx);
+    if (threadIdx.x == 0) text_mask = (unsigned)m;
+  }
+  // The gathers of phase 2 are issued first (up to PRE items per thread, held in registers) so that they
+  // are in flight while phase 1 runs: one memory round trip per block instead of two.
+  constexpr int PRE = 3;
+  const int chunks = mb / N;
+  const int items = kRbTok * chunks;
+  Vec16<T> p1[PRE], p2[PRE];
+  int ps1[PRE], ps2[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int id = min((int)threadIdx.x + k * kRbThreads, items - 1);
+    const int t = id / chunks, c = id - t * chunks;
+    const int sc = min(s0 + t, S - 1);
+    ps1[k] = slot[2 * sc];
+    ps2[k] = slot[2 * sc + 1];
+    p1[k] = load16<T>(dxd + (size_t)max(ps1[k], 0) * M + c0 + c * N);
+    p2[k] = load16<T>(dxd + (size_t)max(ps2[k], 0) * M + c0 + c * N);
+  }
+  __syncthreads();  // dl
+  if constexpr (sizeof(T) == 2) {
+    // phase 1, bf16 activations: each fp32 operand as hi + lo bf16 halves, hi*hi + hi*lo + lo*hi on
+    // v_mfma_f32_32x32x16_bf16 (fp32 accumulate) -- products good to ~2^-17, far below the bf16 rounding
+    // of dh, at a fifth of the fp32 MFMA's issue time
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
     const int i = lane & 31, hh = lane >> 5;
-    const int tok = min(s0 + i, S - 1);
+    bf16x8_t ah[2], al[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = ks * 16 + 8 * hh + j;
+        const float v = e < E ? dl[i][min(e, E - 1)] : 0.f;
+        const __bf16 h = static_cast<__bf16>(v);
+        ah[ks][j] = h;
+        al[ks][j] = static_cast<__bf16>(v - static_cast<float>(h));
+      }
+    const int ntiles = (mb + 31) / 32;
+    for (int tile = wave; tile < ntiles; tile += kRbThreads / 64) {
+      const int col = tile * 32 + i;
+      const float* wp = wg + c0 + min(col, mb - 1);
+      float w[2][8];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[ks][j] = wp[(size_t)min(ks * 16 + 8 * hh + j, E - 1) * M];  // a = 0 masks e >= E
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t bh, bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const __bf16 h = static_cast<__bf16>(w[ks][j]);
+          bh[j] = h;
+          bl[j] = static_cast<__bf16>(w[ks][j] - static_cast<float>(h));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+      }
+      if (col < mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[((r & 3) + 8 * (r >> 2) + 4 * hh) * ld + col] = acc[r];
+      }
+    }
+  } else {  // phase 1, fp32 activations: exact fp32 FMAs
+    const int i = lane & 31, hh = lane >> 5;
     float a[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int e = 2 * j + hh;
-      const float v = dlogits[(size_t)tok * E + min(e, E - 1)];
+      const float v = dl[i][min(e, E - 1)];
       a[j] = e < E ? v : 0.f;
     }
     const int ntiles = (mb + 31) / 32;
@@ -317,35 +393,44 @@ __global__ __launch_bounds__(kRbThreads) void route_bwd_kernel(const T* __restri
     }
   }
   __syncthreads();
-  {  // phase 2: loads are unconditional (clamped) so that several items' gathers are in flight together
-    const int chunks = mb / N;
-    const int items = kRbTok * chunks;
-#pragma unroll 4
-    for (int id = threadIdx.x; id < items; id += kRbThreads) {
-      const int t = id / chunks, c = id - t * chunks;
-      const int s = s0 + t, sc = min(s, S - 1);
-      const int s1 = slot[2 * sc], s2 = slot[2 * sc + 1];
-      const Vec16<T> v1 = load16<T>(dxd + (size_t)max(s1, 0) * M + c0 + c * N);
-      const Vec16<T> v2 = load16<T>(dxd + (size_t)max(s2, 0) * M + c0 + c * N);
-      float* g = G + t * ld + c * N;
-      Vec16<T> o;
+  auto finish = [&](int id, int s1, int s2, const Vec16<T>& v1, const Vec16<T>& v2) {
+    const int t = id / chunks, c = id - t * chunks;
+    const int s = s0 + t;
+    float* g = G + t * ld + c * N;
+    Vec16<T> o;
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const float v = (g[j] + (s1 >= 0 ? v1.get(j) : 0.f)) + (s2 >= 0 ? v2.get(j) : 0.f);
-        o.set(j, v);
-      }
-#pragma unroll
-      for (int j = 0; j < N; ++j) g[j] = s < S ? o.get(j) : 0.f;
-      if (s < S) store16<T>(dh + (size_t)s * M + c0 + c * N, o);
+    for (int j = 0; j < N; ++j) {
+      const float v = (g[j] + (s1 >= 0 ? v1.get(j) : 0.f)) + (s2 >= 0 ? v2.get(j) : 0.f);
+      o.set(j, v);
     }
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = s < S ? o.get(j) : 0.f;
+    if (s < S) store16<T>(dh + (size_t)s * M + c0 + c * N, o);
+  };
+  // phase 2
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const int id = threadIdx.x + k * kRbThreads;
+    if (id < items) finish(id, ps1[k], ps2[k], p1[k], p2[k]);
+  }
+#pragma unroll 2
+  for (int id = threadIdx.x + PRE * kRbThreads; id < items; id += kRbThreads) {  // wide slabs: the rest
+    const int t = id / chunks, c = id - t * chunks;
+    const int sc = min(s0 + t, S - 1);
+    const int s1 = slot[2 * sc], s2 = slot[2 * sc + 1];
+    const Vec16<T> v1 = load16<T>(dxd + (size_t)max(s1, 0) * M + c0 + c * N);
+    const Vec16<T> v2 = load16<T>(dxd + (size_t)max(s2, 0) * M + c0 + c * N);
+    finish(id, s1, s2, v1, v2);
   }
   if (!part) return;  // block-uniform
   __syncthreads();
+  const unsigned tm = text_mask;
   for (int col = threadIdx.x; col < mb; col += kRbThreads) {  // phase 3
     float av = 0.f, at = 0.f;
+#pragma unroll 8
     for (int t = 0; t < kRbTok; ++t) {
       const float v = G[t * ld + col];
-      if (token_modality(min(s0 + t, S - 1), T_, n_vis, mode)) at += v; else av += v;
+      if ((tm >> t) & 1u) at += v; else av += v;
     }
     part[((size_t)blockIdx.x * 2 + 0) * M + c0 + col] = av;
     part[((size_t)blockIdx.x * 2 + 1) * M + c0 + col] = at;
@@ -353,8 +438,9 @@ __global__ __launch_bounds__(kRbThreads) void route_bwd_kernel(const T* __restri
 }
 
 // fixed-order sum of the per-block partials: block = 32 columns x 32 slices of the partial rows
-__global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* __restrict__ part, float* __restrict__ dv,
-                                                                  float* __restrict__ dt, int M, int nchunks) {
+template <typename TO>
+__global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* __restrict__ part, TO* __restrict__ dv,
+                                                                  TO* __restrict__ dt, int M, int nchunks) {
   __shared__ float red[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + tx;   // over 2*M columns: [vision M | text M] per chunk row
@@ -369,8 +455,8 @@ __global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* _
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 32; ++r) s += red[r][tx];
-    if (col < M) { if (dv) dv[col] = s; }
-    else if (dt) dt[col - M] = s;
+    if (col < M) { if (dv) dv[col] = from_f32<TO>(s); }
+    else if (dt) dt[col - M] = from_f32<TO>(s);
   }
 }
 
@@ -457,18 +543,14 @@ extern "C" int eve_combine_bwd(const void* dout, const void* y, const int32_t* s
   EVE_REQUIRE(S > 0 && num_slots > 0, EVE_ERR_ARG, "eve_combine_bwd: bad shape");
   if (int rc = check_rows("eve_combine_bwd", M, dtype)) return rc;
   hipStream_t st = S_(stream);
-  if (dtype == EVE_F32) {
-    hipLaunchKernelGGL((combine_bwd_dy_kernel<float>), dim3(row_grid(num_slots)), dim3(256), 0, st, (const float*)dout,
-                       slot_token, slot_weight, (float*)dy, M, num_slots);
-    hipLaunchKernelGGL((combine_bwd_dw_kernel<float>), dim3(row_grid(S)), dim3(256), 0, st, (const float*)dout,
-                       (const float*)y, slot, d_weight, S, M);
-  } else {
-    hipLaunchKernelGGL((combine_bwd_dy_kernel<bf16_t>), dim3(row_grid(num_slots)), dim3(256), 0, st,
-                       (const bf16_t*)dout, slot_token, slot_weight, (bf16_t*)dy, M, num_slots);
-    hipLaunchKernelGGL((combine_bwd_dw_kernel<bf16_t>), dim3(row_grid(S)), dim3(256), 0, st, (const bf16_t*)dout,
-                       (const bf16_t*)y, slot, d_weight, S, M);
-  }
-  EVE_CHECK_LAUNCH("combine_bwd kernels");
+  const int grid = max(1, min(ceil_div(S, 8), 8192));
+  if (dtype == EVE_F32)
+    hipLaunchKernelGGL((combine_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)y, slot,
+                       slot_token, slot_weight, (float*)dy, d_weight, S, M, num_slots);
+  else
+    hipLaunchKernelGGL((combine_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y,
+                       slot, slot_token, slot_weight, (bf16_t*)dy, d_weight, S, M, num_slots);
+  EVE_CHECK_LAUNCH("combine_bwd_kernel");
   return EVE_OK;
 }
 
@@ -497,7 +579,7 @@ extern "C" int eve_embed_grad(const void* dh, float* dvision, float* dtext, int 
     hipLaunchKernelGGL((embed_grad_partial_kernel<bf16_t>), dim3(nchunks), dim3(128), 0, st, (const bf16_t*)dh, part,
                        S, T, n_vis, mode, M, kEmbedTS);
   EVE_CHECK_LAUNCH("embed_grad_partial_kernel");
-  hipLaunchKernelGGL(embed_grad_final_kernel, dim3(ceil_div(2 * M, 32)), dim3(256), 0, st, part, dvision, dtext, M,
+  hipLaunchKernelGGL(embed_grad_final_kernel<float>, dim3(ceil_div(2 * M, 32)), dim3(256), 0, st, part, dvision, dtext, M,
                      nchunks);
   EVE_CHECK_LAUNCH("embed_grad_final_kernel");
   return EVE_OK;
@@ -508,9 +590,10 @@ static inline int route_bwd_slab(int M) { return M <= 256 ? ceil_div(M, 32) * 32
 static inline size_t route_bwd_lds(int M) { return (size_t)kRbTok * (route_bwd_slab(M) + 4) * sizeof(float); }
 
 extern "C" int eve_route_bwd(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh,
-                             float* dvision, float* dtext, int S, int T, int n_vis, int mode, int M, int E, int dtype,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+                             void* dvision, void* dtext, int S, int T, int n_vis, int mode, int M, int E, int dtype,
+                             int embed_dtype, void* workspace, size_t workspace_bytes, void* stream) {
   EVE_REQUIRE(dxd && slot && dlogits && wg && dh, EVE_ERR_ARG, "eve_route_bwd: null pointer");
+  EVE_REQUIRE(embed_dtype == EVE_F32 || embed_dtype == EVE_BF16, EVE_ERR_ARG, "eve_route_bwd: bad embed_dtype %d", embed_dtype);
   EVE_REQUIRE(S > 0 && E > 0, EVE_ERR_ARG, "eve_route_bwd: bad shape");
   if (int rc = check_rows("eve_route_bwd", M, dtype)) return rc;
   const bool want_embed = mode != EVE_MODE_NONE && (dvision || dtext);
@@ -522,7 +605,22 @@ extern "C" int eve_route_bwd(const void* dxd, const int32_t* slot, const float* 
   }
   if (E > 32 || route_bwd_lds(M) > 160 * 1024) {  // shapes the fused kernel does not cover: the two-pass path
     if (int rc = eve_dispatch_bwd(dxd, slot, dlogits, wg, dh, S, M, E, dtype, stream)) return rc;
-    if (want_embed) return eve_embed_grad(dh, dvision, dtext, S, T, n_vis, mode, M, dtype, workspace, workspace_bytes, stream);
+    if (!want_embed) return EVE_OK;
+    if (embed_dtype == EVE_F32)
+      return eve_embed_grad(dh, (float*)dvision, (float*)dtext, S, T, n_vis, mode, M, dtype, workspace, workspace_bytes, stream);
+    // bf16 embedding gradients: the same two stages, the final sums rounded once
+    const int nchunks = ceil_div(S, kEmbedTS);
+    float* part = static_cast<float*>(workspace);
+    if (dtype == EVE_F32)
+      hipLaunchKernelGGL((embed_grad_partial_kernel<float>), dim3(nchunks), dim3(128), 0, S_(stream), (const float*)dh,
+                         part, S, T, n_vis, mode, M, kEmbedTS);
+    else
+      hipLaunchKernelGGL((embed_grad_partial_kernel<bf16_t>), dim3(nchunks), dim3(128), 0, S_(stream),
+                         (const bf16_t*)dh, part, S, T, n_vis, mode, M, kEmbedTS);
+    EVE_CHECK_LAUNCH("embed_grad_partial_kernel");
+    hipLaunchKernelGGL(embed_grad_final_kernel<bf16_t>, dim3(ceil_div(2 * M, 32)), dim3(256), 0, S_(stream), part,
+                       (bf16_t*)dvision, (bf16_t*)dtext, M, nchunks);
+    EVE_CHECK_LAUNCH("embed_grad_final_kernel");
     return EVE_OK;
   }
   static_assert(kRbTok == kEmbedTS, "eve_embed_grad_workspace_bytes sizes the partials of both paths");
@@ -547,7 +645,12 @@ extern "C" int eve_route_bwd(const void* dxd, const int32_t* slot, const float* 
 #undef EVE_RB_LAUNCH
   EVE_CHECK_LAUNCH("route_bwd_kernel");
   if (want_embed) {
-    hipLaunchKernelGGL(embed_grad_final32_kernel, dim3(ceil_div(2 * M, 32)), dim3(1024), 0, st, part, dvision, dtext, M, nblk);
+    if (embed_dtype == EVE_F32)
+      hipLaunchKernelGGL(embed_grad_final32_kernel<float>, dim3(ceil_div(2 * M, 32)), dim3(1024), 0, st, part,
+                         (float*)dvision, (float*)dtext, M, nblk);
+    else
+      hipLaunchKernelGGL(embed_grad_final32_kernel<bf16_t>, dim3(ceil_div(2 * M, 32)), dim3(1024), 0, st, part,
+                         (bf16_t*)dvision, (bf16_t*)dtext, M, nblk);
     EVE_CHECK_LAUNCH("embed_grad_final32_kernel");
   }
   return EVE_OK;

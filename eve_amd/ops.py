@@ -123,7 +123,8 @@ def gumbel_from_uniform(u: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int) -> Routing:
+def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int, noise_is_uniform: bool = False) -> Routing:
+    """`noise`: Gumbel variates [S,E], or (noise_is_uniform) the torch.rand draws they are made of."""
     _chk(logits, "logits", torch.float32), _chk(noise, "noise", torch.float32)
     S, E = logits.shape
     assert noise.shape == logits.shape
@@ -132,11 +133,11 @@ def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int) -> Routing:
     f32 = dict(dtype=torch.float32, device=dev)
     r = Routing(S, E, C, torch.empty(S, E, **f32), torch.empty(S, 2, **i32), torch.empty(S, 2, **i32),
                 torch.empty(S, 2, **i32), torch.empty(S, 2, **f32), torch.empty(E * C, **i32),
-                torch.zeros(E * C, **f32), torch.empty(E, dtype=torch.int64, device=dev), torch.empty(E, **i32),
+                torch.empty(E * C, **f32), torch.empty(E, dtype=torch.int64, device=dev), torch.empty(E, **i32),
                 torch.empty(1, **f32))
     nbytes = _lib.load().eve_gate_workspace_bytes(S, E)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    PROFILE.call("eve_gate_top2_fwd", _p(logits), _p(noise), S, E, C, _p(r.gates), _p(r.idx), _p(r.loc), _p(r.slot),
+    PROFILE.call("eve_gate_top2_fwd", _p(logits), _p(noise), 1 if noise_is_uniform else 0, S, E, C, _p(r.gates), _p(r.idx), _p(r.loc), _p(r.slot),
               _p(r.weight), _p(r.slot_token), _p(r.slot_weight), _p(r.exp_counts), _p(r.rows), _p(r.l_aux), _p(ws),
               nbytes, _stream())
     return r
@@ -182,8 +183,10 @@ def dispatch_bwd(dxd: torch.Tensor, slot: torch.Tensor, dlogits, wg, S: int) -> 
     return dh
 
 
-def route_bwd(dxd, slot, dlogits, wg, S: int, T: int, n_vis: int, mode: int, want_v: bool, want_t: bool):
-    """dispatch_bwd + embed_grad in one pass: -> (dh [S,M], dvision|None, dtext|None)."""
+def route_bwd(dxd, slot, dlogits, wg, S: int, T: int, n_vis: int, mode: int, want_v: bool, want_t: bool,
+              embed_dtype: torch.dtype = torch.float32):
+    """dispatch_bwd + embed_grad in one pass: -> (dh [S,M], dvision|None, dtext|None); the embedding
+    gradients are stored as `embed_dtype` (fp32, or bf16 for bf16 parameters)."""
     _chk(dxd, "dxd"), _chk(slot, "slot", torch.int32), _chk(dlogits, "dlogits", torch.float32)
     _chk(wg, "wg", torch.float32)
     M = dxd.shape[-1]
@@ -192,12 +195,12 @@ def route_bwd(dxd, slot, dlogits, wg, S: int, T: int, n_vis: int, mode: int, wan
     dh = torch.empty(S, M, dtype=dxd.dtype, device=dev)
     want_v = want_v and mode != _lib.MODE_NONE
     want_t = want_t and mode != _lib.MODE_NONE
-    dv = torch.empty(M, dtype=torch.float32, device=dev) if want_v else None
-    dt = torch.empty(M, dtype=torch.float32, device=dev) if want_t else None
+    dv = torch.empty(M, dtype=embed_dtype, device=dev) if want_v else None
+    dt = torch.empty(M, dtype=embed_dtype, device=dev) if want_t else None
     nbytes = _lib.load().eve_embed_grad_workspace_bytes(S, M) if (want_v or want_t) else 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     PROFILE.call("eve_route_bwd", _p(dxd), _p(slot), _p(dlogits), _p(wg), _p(dh), _p(dv), _p(dt), S, T, n_vis, mode, M, E,
-                 _dt(dxd), _p(ws), nbytes, _stream())
+                 _dt(dxd), _DTYPES[embed_dtype], _p(ws), nbytes, _stream())
     return dh, dv, dt
 
 

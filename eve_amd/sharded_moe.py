@@ -54,6 +54,20 @@ def _fused_gumbel_matches_torch(device: torch.device) -> bool:
         torch.cuda.set_rng_state(gen_state, device)
 
 
+def _fused_gumbel_usable(device: torch.device) -> bool:
+    """True when the in-kernel Gumbel transform may stand in for torch's sampler on `device` (checked once,
+    bit for bit, outside graph capture)."""
+    ok = _fused_gumbel_ok.get(device)
+    if ok is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        ok = _fused_gumbel_ok[device] = _fused_gumbel_matches_torch(device)
+        if not ok:
+            import warnings
+            warnings.warn("eve_amd: fused Gumbel kernel differs from torch.distributions on this build; using torch's")
+    return ok
+
+
 def gumbel_rsample(shape, device: torch.device) -> Tensor:
     """One Gumbel(0,1) draw of `shape` from the GLOBAL torch generator of `device`, value for value the
     draw the reference makes (sharded_moe.py:70-77): the same single `torch.rand` consumption of the
@@ -65,17 +79,24 @@ def gumbel_rsample(shape, device: torch.device) -> Tensor:
         return _torch_gumbel(shape, device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    ok = _fused_gumbel_ok.get(device)
-    if ok is None:
-        if torch.cuda.is_current_stream_capturing():
-            return _torch_gumbel(shape, device)
-        ok = _fused_gumbel_ok[device] = _fused_gumbel_matches_torch(device)
-        if not ok:
-            import warnings
-            warnings.warn("eve_amd: fused Gumbel kernel differs from torch.distributions on this build; using torch's")
-    if not ok:
+    if not _fused_gumbel_usable(device):
         return _torch_gumbel(shape, device)
     return ops.gumbel_from_uniform(torch.rand(tuple(shape), dtype=torch.float32, device=device))
+
+
+_own_gumbel_rsample = gumbel_rsample
+
+
+def _draw_noise(shape, device: torch.device) -> Tuple[Tensor, bool]:
+    """(noise, is_uniform) for the gate kernel: the torch.rand draw itself when the kernel may apply the
+    Gumbel transform (the same generator consumption as `gumbel_rsample`), else finished Gumbel variates
+    -- also when a caller has replaced this module's `gumbel_rsample`, as the goldens' scripts do."""
+    device = torch.device(device)
+    if device.index is None and device.type == "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+    if gumbel_rsample is _own_gumbel_rsample and device.type == "cuda" and _fused_gumbel_usable(device):
+        return torch.rand(tuple(shape), dtype=torch.float32, device=device), True
+    return gumbel_rsample(shape, device=device), False
 
 
 def _capacity(num_tokens: int, num_experts: int, capacity_factor: float, min_capacity: int) -> int:
@@ -116,8 +137,8 @@ class _GateFn(torch.autograd.Function):
     """logits, noise -> (weight [S,2], l_aux) + index tensors; HIP eve_gate_top2_fwd/bwd."""
 
     @staticmethod
-    def forward(ctx, logits: Tensor, noise: Tensor, C: int):  # type: ignore[override]
-        r = ops.gate_top2(logits.contiguous(), noise.contiguous(), C)
+    def forward(ctx, logits: Tensor, noise: Tensor, C: int, noise_is_uniform: bool = False):  # type: ignore[override]
+        r = ops.gate_top2(logits.contiguous(), noise.contiguous(), C, noise_is_uniform)
         ctx.routing = r
         ctx.set_materialize_grads(False)  # no zero tensors for the index outputs' "gradients"
         outs = (r.weight, r.l_aux.view(()), r.slot, r.slot_token, r.slot_weight, r.rows, r.exp_counts, r.idx, r.loc)
@@ -130,7 +151,7 @@ class _GateFn(torch.autograd.Function):
         if d_weight is None:
             d_weight = torch.zeros_like(r.weight)
         dl = None if d_l_aux is None else d_l_aux.reshape(1).float().contiguous()
-        return ops.gate_top2_bwd(r, d_weight.contiguous(), dl), None, None
+        return ops.gate_top2_bwd(r, d_weight.contiguous(), dl), None, None, None
 
 
 class _RouteDispatchFn(torch.autograd.Function):
@@ -141,7 +162,8 @@ class _RouteDispatchFn(torch.autograd.Function):
     + gate-Linear input gradient), dwg and the two modality-embedding gradients."""
 
     @staticmethod
-    def forward(ctx, h, wg, vemb, temb, noise, n_vis, mode, cap_factor, min_capacity):  # type: ignore[override]
+    def forward(ctx, h, wg, vemb, temb, noise, n_vis, mode, cap_factor, min_capacity,  # type: ignore[override]
+                noise_is_uniform=False):
         B, T, M = h.shape
         S = B * T
         h2d = h.contiguous().view(S, M)
@@ -151,7 +173,7 @@ class _RouteDispatchFn(torch.autograd.Function):
         E = wg32.shape[0]
         logits = ops.gate_logits(h2d, ve, te, wg32, T, n_vis, mode)
         C = ops.capacity(S, E, cap_factor, min_capacity)
-        r = ops.gate_top2(logits, noise.contiguous(), C)
+        r = ops.gate_top2(logits, noise.contiguous(), C, noise_is_uniform)
         xd = ops.dispatch_fwd(h2d, ve, te, r.slot_token, T, n_vis, mode)
         ctx.routing, ctx.dims = r, (B, T, M, n_vis, mode)
         ctx.set_materialize_grads(False)  # no zero tensors for the index outputs' "gradients"
@@ -176,11 +198,16 @@ class _RouteDispatchFn(torch.autograd.Function):
         wg_dt, v_dt, t_dt = ctx.param_dtypes
         want_v = mode in (_lib.MODE_VL, _lib.MODE_VISION) and ctx.needs_input_grad[2]
         want_t = mode in (_lib.MODE_VL, _lib.MODE_TEXT) and ctx.needs_input_grad[3]
-        dh, dv, dt = ops.route_bwd(dxd.contiguous(), r.slot, dlogits, wg32, S, T, n_vis, mode, want_v, want_t)
+        e_dt = v_dt if v_dt is not None else t_dt
+        fused_dt = e_dt if e_dt in (torch.float32, torch.bfloat16) and v_dt in (None, e_dt) and t_dt in (None, e_dt) \
+            else torch.float32
+        dh, dv, dt = ops.route_bwd(dxd.contiguous(), r.slot, dlogits, wg32, S, T, n_vis, mode, want_v, want_t, fused_dt)
         dwg = ops.gate_wgrad(h2d, ve, te, dlogits, T, n_vis, mode).to(wg_dt) if ctx.needs_input_grad[1] else None
-        dv = None if dv is None else dv.to(v_dt)
-        dt = None if dt is None else dt.to(t_dt)
-        return dh.view(B, T, M), dwg, dv, dt, None, None, None, None, None
+        if dv is not None and dv.dtype != v_dt:
+            dv = dv.to(v_dt)
+        if dt is not None and dt.dtype != t_dt:
+            dt = dt.to(t_dt)
+        return dh.view(B, T, M), dwg, dv, dt, None, None, None, None, None, None
 
 
 class _CombineFn(torch.autograd.Function):
@@ -210,10 +237,11 @@ def top2gating(logits: Tensor, capacity_factor: float, min_capacity: int,
     builds them.  `noise` overrides the Gumbel draw of :186 (tests)."""
     S, E = logits.shape
     logits = logits.float()
+    is_uniform = False
     if noise is None:
-        noise = gumbel_rsample(logits.shape, device=logits.device)
+        noise, is_uniform = _draw_noise(logits.shape, logits.device)
     C = ops.capacity(S, E, capacity_factor, min_capacity)
-    weight, l_aux, slot, _, _, _, exp_counts, _, _ = _GateFn.apply(logits, noise, C)
+    weight, l_aux, slot, _, _, _, exp_counts, _, _ = _GateFn.apply(logits, noise, C, is_uniform)
     keep = slot >= 0
     combine = torch.zeros(S, E * C, dtype=torch.float32, device=logits.device)
     combine = combine.scatter(1, slot.clamp(min=0).long(), weight * keep)
@@ -375,15 +403,17 @@ class MOELayer(nn.Module):
         E = gate.num_experts if hasattr(gate, "num_experts") else gate.wg.weight.shape[0]
         noise = self.noise_override
         self.noise_override = None
+        is_uniform = False
         if noise is None:
-            noise = gumbel_rsample((S, E), device=h.device)
+            noise, is_uniform = _draw_noise((S, E), h.device)
         if gate.noisy_gate_policy == 'Jitter' and self.training:
             raise NotImplementedError("eve_amd.MOELayer: noisy_gate_policy='Jitter' is not used by EVE and is only "
                                       "supported through TopKGate.forward")
         n_vis = int(self.num_vision_tokens) if has_embed else 0
 
         xd, weight, l_aux, slot, slot_token, slot_weight, rows, exp_counts = _RouteDispatchFn.apply(
-            h, gate.wg.weight, vemb_in, temb_in, noise, n_vis, code, gate.active_capacity_factor(), gate.min_capacity)
+            h, gate.wg.weight, vemb_in, temb_in, noise, n_vis, code, gate.active_capacity_factor(), gate.min_capacity,
+            is_uniform)
         self.l_aux = l_aux
         self.exp_counts = _host_counts(exp_counts, self.blocking_exp_counts)
         self.last_slot = slot  # [S,2] int32 token -> slot map of the latest forward (diagnostics)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 2
+#define EVE_MOE_ABI_VERSION 3
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -86,10 +86,14 @@ size_t eve_gate_workspace_bytes(int S, int E);
  *   rows       [E]    min(C, first + second choices): slots [0,rows) of expert e are the
  *                     only ones that can be occupied
  *   l_aux      [1]    load-balance loss                                       (:202-204)
+ * `noise` holds the Gumbel variates themselves (noise_is_uniform == 0) or the standard-uniform draws in
+ * [0,1) they are made of (noise_is_uniform != 0; transformed inside the kernel with the arithmetic of
+ * eve_gumbel_from_uniform, bit for bit).  slot_weight needs no clearing by the caller.
  * Routing indices and drops are bit-exact w.r.t. the reference for identical
  * (logits, noise); fp outputs agree to fp32 rounding.  Deterministic (no atomics). */
-int eve_gate_top2_fwd(const float* logits, const float* noise, int S, int E, int C, float* gates, int32_t* idx,
-                      int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token, float* slot_weight,
+int eve_gate_top2_fwd(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C,
+                      float* gates, int32_t* idx, int32_t* loc, int32_t* slot, float* weight,
+                      int32_t* slot_token, float* slot_weight,
                       int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace, size_t workspace_bytes,
                       void* stream);
 
@@ -133,11 +137,13 @@ int eve_embed_grad(const void* dh, float* dvision, float* dtext, int S, int T, i
 
 /* eve_dispatch_bwd and eve_embed_grad in one pass over dh (the backward of the routing front end,
  * models/sharded_moe.py:350-367 as autograd differentiates it): dh as eve_dispatch_bwd (dlogits and wg
- * required), and -- when mode != EVE_MODE_NONE -- dvision / dtext [M] fp32 as eve_embed_grad (either may
- * be NULL).  workspace: eve_embed_grad_workspace_bytes(S, M) (unused when no embedding gradient is wanted). */
+ * required), and -- when mode != EVE_MODE_NONE -- dvision / dtext [M] as eve_embed_grad (either may be
+ * NULL), stored as embed_dtype (EVE_F32, or EVE_BF16: the fp32 sums rounded once, what a bf16 parameter's
+ * gradient holds).  workspace: eve_embed_grad_workspace_bytes(S, M) (unused when no embedding gradient
+ * is wanted). */
 int eve_route_bwd(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh,
-                  float* dvision, float* dtext, int S, int T, int n_vis, int mode, int M, int E, int dtype,
-                  void* workspace, size_t workspace_bytes, void* stream);
+                  void* dvision, void* dtext, int S, int T, int n_vis, int mode, int M, int E, int dtype,
+                  int embed_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[s,:] = weight[s,0]*y[slot[s,0],:] + weight[s,1]*y[slot[s,1],:]  (fp32 accumulate).
  * Replaces einsum("sec,ecm->sm", combine_weights, expert_output), models/sharded_moe.py:377. */

@@ -144,3 +144,35 @@ def test_fused_gumbel_is_torch_gumbel_bit_for_bit():
     tiny, eps = torch.finfo(torch.float32).tiny, torch.finfo(torch.float32).eps
     u = tiny + r * ((1.0 - eps) - tiny)
     assert torch.equal(ops.gumbel_from_uniform(r), -torch.log(-torch.log(u)))
+
+
+@pytest.mark.parametrize("S,E", [(15168, 32), (1896, 32), (130, 32), (77, 5), (64, 1), (300, 40)])
+def test_gate_with_uniform_draws_equals_gate_with_gumbel_noise(S, E):
+    """eve_gate_top2_fwd fed the torch.rand draws (transform inside the kernel) vs fed the finished Gumbel
+    variates of the same draws: every output identical, bit for bit."""
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(S * 31 + E)
+    logits = torch.randn(S, E, generator=g).to(dev)
+    u = torch.rand(S, E, generator=g).to(dev)
+    u[0, 0] = 0.0
+    u[-1, -1] = 1.0 - 2.0 ** -24
+    C = ops.capacity(S, E, 1.0, 4)
+    a = ops.gate_top2(logits, u, C, noise_is_uniform=True)
+    b = ops.gate_top2(logits, ops.gumbel_from_uniform(u), C)
+    torch.cuda.synchronize()
+    for name in ("gates", "idx", "loc", "slot", "weight", "slot_token", "slot_weight", "exp_counts", "rows", "l_aux"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_layer_draws_noise_like_the_reference_generator():
+    """MOELayer's in-kernel Gumbel path consumes the generator exactly like gumbel_rsample and routes like it."""
+    from eve_amd import sharded_moe as sm
+    dev = torch.device("cuda", 0)
+    assert sm._fused_gumbel_usable(dev)
+    torch.manual_seed(7)
+    u, is_u = sm._draw_noise((500, 32), dev)
+    nxt = torch.rand(3, device=dev)
+    torch.manual_seed(7)
+    n = sm.gumbel_rsample((500, 32), dev)
+    nxt2 = torch.rand(3, device=dev)
+    assert is_u and torch.equal(ops.gumbel_from_uniform(u), n) and torch.equal(nxt, nxt2)

@@ -175,6 +175,10 @@ def test_route_bwd_matches_two_pass(dtype, B, T, n_vis, M, E, mode):
     torch.cuda.synchronize()
     torch.testing.assert_close(dv, dv_ref, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dt, dt_ref, rtol=1e-5, atol=1e-5)
+    # bf16 embedding gradients: the same fp32 sums, rounded once
+    _, dv16, dt16 = ops.route_bwd(*args, S, T, n_vis, mcode, True, True, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(dv16, dv.to(torch.bfloat16)) and torch.equal(dt16, dt.to(torch.bfloat16))
     is_text = torch.tensor([orc_is_text(s, T, n_vis, mode) for s in range(S)])
     d64 = dh.cpu().double()
     torch.testing.assert_close(dv.cpu().double(), d64[~is_text].sum(0), rtol=1e-4, atol=1e-4)
