@@ -201,7 +201,8 @@ template <bool E32>
 __global__ __launch_bounds__(256) void gate_select32_kernel(
     const float* __restrict__ logits, const float* __restrict__ noise, int noise_is_uniform, int S, int E,
     float* __restrict__ gates, int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank,
-    float* __restrict__ gsum, int32_t* __restrict__ slot_token, float* __restrict__ slot_weight, int num_slots) {
+    float* __restrict__ gsum, int32_t* __restrict__ slot_token, float* __restrict__ slot_weight, int num_slots,
+    int block_major) {
   __shared__ int ci1[kGateBlock], ci2[kGateBlock];
   __shared__ float tile[kGateBlock][33];
   __shared__ float gpart[8][32];
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
     float p = gpart[0][threadIdx.x];
 #pragma unroll
     for (int r = 1; r < 8; ++r) p += gpart[r][threadIdx.x];
-    gsum[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = p;
+    gsum[block_major ? (size_t)blockIdx.x * E + threadIdx.x : (size_t)threadIdx.x * gridDim.x + blockIdx.x] = p;
   }
 
   // part B: lane = token
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
     const unsigned long long m2 = __ballot(i2 == x);
     if (i1 == x) rank[2 * s] = __popcll(m1 & lt);
     if (i2 == x) rank[2 * s + 1] = __popcll(m2 & lt);
-    if (lane == 0) {
-      hist[(size_t)x * gridDim.x + blockIdx.x] = __popcll(m1);
-      hist[(size_t)(E + x) * gridDim.x + blockIdx.x] = __popcll(m2);
+    if (lane == 0) {  // hist[2E][nblk] for the scan kernel, hist[nblk][2E] for gate_assign32_kernel
+      hist[block_major ? (size_t)blockIdx.x * 2 * E + x : (size_t)x * gridDim.x + blockIdx.x] = __popcll(m1);
+      hist[block_major ? (size_t)blockIdx.x * 2 * E + E + x : (size_t)(E + x) * gridDim.x + blockIdx.x] = __popcll(m2);
     }
   }
   if (wave == 0 && s < S) {
@@ -444,6 +445,108 @@ __global__ __launch_bounds__(kGateBlock) void gate_assign_kernel(
   const int nblk = gridDim.x;
   const int l1 = boff[(size_t)i1 * nblk + blockIdx.x] + rank[2 * s];
   const int l2 = boff[(size_t)(E + i2) * nblk + blockIdx.x] + rank[2 * s + 1] + tot[i2];  // behind ALL 1st choices
+  const bool k1 = l1 < C, k2 = l2 < C;
+  const float g1 = k1 ? gates[(size_t)s * E + i1] : 0.f;
+  const float g2 = k2 ? gates[(size_t)s * E + i2] : 0.f;
+  const float den = fmaxf(g1 + g2, kEps);
+  const float w1 = g1 / den, w2 = g2 / den;
+  const int s1 = (k1 && w1 != 0.f) ? i1 * C + l1 : -1;
+  const int s2 = (k2 && w2 != 0.f) ? i2 * C + l2 : -1;
+  loc[2 * s] = l1;
+  loc[2 * s + 1] = l2;
+  slot[2 * s] = s1;
+  slot[2 * s + 1] = s2;
+  weight[2 * s] = w1;
+  weight[2 * s + 1] = w2;
+  if (s1 >= 0) { slot_token[s1] = s; slot_weight[s1] = w1; }
+  if (s2 >= 0) { slot_token[s2] = s; slot_weight[s2] = w2; }
+}
+
+// Passes 2 + 3 in one kernel for E <= 32 and at most 256 blocks (S <= 16384): every block derives its own
+// queue offsets -- for each (choice, expert) column of the BLOCK-MAJOR histogram hist[blk][2E], the sum over
+// the blocks before it and the total -- with 512 threads (thread = column x one eighth of the blocks, up to
+// 32 independent coalesced loads each, partials combined through LDS in a fixed order), then assigns its
+// 64 tokens as gate_assign_kernel does.  Block 0 also writes exp_counts, rows and l_aux (gsum is block-major
+// [blk][E] here as well).  hist is re-read once per block (L2-resident, nblk^2 * 2E ints in all); that
+// saves the single-block scan kernel, its launch and one dependent pass.  The scan + assign pair remains
+// for longer inputs and for E > 32.
+constexpr int kAssign32MaxBlocks = 256;
+__global__ __launch_bounds__(512) void gate_assign32_kernel(
+    const float* __restrict__ gates, const int32_t* __restrict__ idx, const int32_t* __restrict__ rank,
+    const int32_t* __restrict__ hist, const float* __restrict__ gsum, int S, int E, int C, int32_t* __restrict__ loc,
+    int32_t* __restrict__ slot, float* __restrict__ weight, int32_t* __restrict__ slot_token,
+    float* __restrict__ slot_weight, int64_t* __restrict__ exp_counts, int32_t* __restrict__ rows,
+    float* __restrict__ l_aux) {
+  __shared__ int32_t pbefore[8][64], pall[8][64];
+  __shared__ int32_t pre[64], tot[64];
+  __shared__ float gpart[16][32];
+  __shared__ float term[32];
+  const int nblk = gridDim.x, me = blockIdx.x;
+  {
+    const int r = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int per = (nblk + 7) >> 3, b0 = part * per, b1 = min(nblk, b0 + per);
+    const int rc = min(r, 2 * E - 1);
+    int v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = hist[(size_t)min(b0 + k, nblk - 1) * (2 * E) + rc];  // clamped, masked below
+    int before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const int b = b0 + k;
+      all += b < b1 ? v[k] : 0;
+      before += (b < b1 && b < me) ? v[k] : 0;
+    }
+    pbefore[part][r] = before;
+    pall[part][r] = all;
+  }
+  float gacc = 0.f;
+  if (me == 0) {  // column sums of the gates over all blocks: 16 partial sums per expert, fixed order
+    const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int per = (nblk + 15) >> 4, b0 = part * per, b1 = min(nblk, b0 + per);
+    const int ec = min(e, E - 1);
+    float g[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] = gsum[(size_t)min(b0 + k, nblk - 1) * E + ec];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gacc += (b0 + k < b1) ? g[k] : 0.f;
+    gpart[part][e] = gacc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    int before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      before += pbefore[q][threadIdx.x];
+      all += pall[q][threadIdx.x];
+    }
+    pre[threadIdx.x] = before;
+    tot[threadIdx.x] = all;
+  }
+  __syncthreads();
+  if (me == 0) {
+    // l_aux = mean_e(mean_s gates * mean_s mask1) * E * E     (sharded_moe.py:202-204)
+    if (threadIdx.x < E) {
+      const int e = threadIdx.x;
+      float gs = gpart[0][e];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) gs += gpart[q][e];
+      term[e] = (gs / (float)S) * ((float)tot[e] / (float)S);
+      exp_counts[e] = (int64_t)tot[e];
+      const int filled = tot[e] + tot[E + e];
+      rows[e] = filled < C ? filled : C;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float acc = 0.f;
+      for (int e = 0; e < E; ++e) acc += term[e];
+      l_aux[0] = acc / (float)E * (float)E * (float)E;
+    }
+  }
+  const int s = me * kGateBlock + threadIdx.x;
+  if (threadIdx.x >= kGateBlock || s >= S) return;
+  const int i1 = idx[2 * s], i2 = idx[2 * s + 1];
+  const int l1 = pre[i1] + rank[2 * s];
+  const int l2 = pre[E + i2] + rank[2 * s + 1] + tot[i2];  // behind ALL 1st choices
   const bool k1 = l1 < C, k2 = l2 < C;
   const float g1 = k1 ? gates[(size_t)s * E + i1] : 0.f;
   const float g2 = k2 ? gates[(size_t)s * E + i2] : 0.f;
@@ -1094,13 +1197,14 @@ extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int no
   float* gsum = reinterpret_cast<float*>(ws + w.gsum);
   int32_t* tot = reinterpret_cast<int32_t*>(ws + w.tot);
   hipStream_t st = S_(stream);
+  const int fused_assign = E <= 32 && w.nblk <= kAssign32MaxBlocks ? 1 : 0;
   if (E <= 32) {
     if (E == 32)
       hipLaunchKernelGGL(gate_select32_kernel<true>, dim3(w.nblk), dim3(256), 0, st, logits, noise, noise_is_uniform, S, E,
-                         gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C);
+                         gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C, fused_assign);
     else
       hipLaunchKernelGGL(gate_select32_kernel<false>, dim3(w.nblk), dim3(256), 0, st, logits, noise, noise_is_uniform, S, E,
-                         gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C);
+                         gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C, fused_assign);
     EVE_CHECK_LAUNCH("gate_select32_kernel");
   } else {
     const int use_tile = E <= 128 ? 1 : 0;
@@ -1108,6 +1212,12 @@ extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int no
     hipLaunchKernelGGL(gate_select_kernel, dim3(w.nblk), dim3(kGateBlock), lds1, st, logits, noise, noise_is_uniform, S, E,
                        gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C, use_tile);
     EVE_CHECK_LAUNCH("gate_select_kernel");
+  }
+  if (fused_assign) {
+    hipLaunchKernelGGL(gate_assign32_kernel, dim3(w.nblk), dim3(512), 0, st, gates, idx, rank, hist, gsum, S, E, C, loc,
+                       slot, weight, slot_token, slot_weight, exp_counts, rows, l_aux);
+    EVE_CHECK_LAUNCH("gate_assign32_kernel");
+    return EVE_OK;
   }
   const size_t lds2 = (size_t)4 * E * 4;
   hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(1024), lds2, st, hist, boff, gsum, tot, exp_counts, rows, l_aux, S,
