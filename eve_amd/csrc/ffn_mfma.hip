@@ -201,6 +201,58 @@ __device__ __forceinline__ bf16x8 frag_load16(const char* tile, int r0, int ks, 
   }
 }
 
+// ---- transposed fragment reads of the ping-pong kernels ---------------------------------------------------
+// ds_read_b64_tr_b16 as inline asm.  Through the builtin the compiler's waitcnt pass puts an s_waitcnt
+// vmcnt(0) in front of every such read that follows an LDS-DMA in program order (it cannot see that the
+// DMA targets another ring slot), which forbids issuing the fetch of a phase before or between its reads;
+// an asm read carries no such dependence, so the fetch is interleaved with the reads and both latencies
+// overlap.  The price: the compiler does not count these reads in lgkmcnt, so every user ends its read
+// phase with `s_waitcnt lgkmcnt(0)` followed by frag_fence() on the registers before their first use.
+// Address of a lane inside the tile for the 32-column sub-tile at r0 (see frag_load): k-row 8h + q of K
+// sub-step 0, columns from 4p; K sub-step ks and the second half of the fragment are immediate offsets.
+template <int W>
+__device__ __forceinline__ uint32_t tr_lane_offset(int r0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = lane >> 5;
+  const int e = r0 + 16 * (g & 1) + 4 * p;
+  return (uint32_t)(col_tile_off<W>(8 * h + q, e >> 3) + ((e & 7) << 1));
+}
+__device__ __forceinline__ uint32_t lds_addr(const char* p) {
+  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+template <int W>
+__device__ __forceinline__ bf16x8 frag_load_tr(uint32_t addr, int ks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  s16x4 v0, v1;
+#define EVE_TR_CASE(n)                                                                                       \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v0) : "v"(addr), "n"((n) * 16 * 2 * W));          \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v1) : "v"(addr), "n"(((n) * 16 + 4) * 2 * W));
+  switch (ks) {  // ks is a constant after unrolling; the offset must be one for the assembler
+    case 0: EVE_TR_CASE(0) break;
+    case 1: EVE_TR_CASE(1) break;
+    case 2: EVE_TR_CASE(2) break;
+    default: EVE_TR_CASE(3) break;
+  }
+#undef EVE_TR_CASE
+  s16x8 w = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, w);
+#else
+  return bf16x8{};
+#endif
+}
+// orders the first use of asm-loaded fragments after the s_waitcnt that precedes this call
+template <int NA, int NB, int KI>
+__device__ __forceinline__ void frag_fence(bf16x8 (&fa)[KI][NA], bf16x8 (&fb)[KI][NB]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int ks = 0; ks < KI; ++ks) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(fa[ks][i]));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(fb[ks][j]));
+  }
+#endif
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t w, int hi) {
   return __uint_as_float(hi ? (w & 0xffff0000u) : (w << 16));
 }
@@ -674,22 +726,34 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
       const char* sb = smem + sl_b * kSub;
       char* slot = smem + sl_f * kSub;
       const uint32_t origin = my_origin(tf);
-      // With plain (non-transposed) fragment reads the fetch is interleaved with them: the DMA issue is
-      // paced by the CU's texture path and the reads by the LDS, so side by side the phase is shorter.
-#ifdef EVE_PP_STAMP
-      constexpr bool kInterleave = false;
-#else
-      constexpr bool kInterleave = !A_COL && !B_COL && !BIAS_GRAD;
-#endif
+      // The fetch is interleaved with the fragment reads: the DMA issue is paced by the CU's texture path
+      // and the reads by the LDS, so side by side the phase is shorter (not with the bias-gradient reads,
+      // plain loads that the compiler would make wait for the fetch).
+      constexpr bool kInterleave = !BIAS_GRAD && !kM16;
+      // lane addresses of the transposed reads (asm reads, see frag_load_tr)
+      uint32_t ta[NTM], tb[NTN];
+      if constexpr (A_COL && !kM16) {
+#pragma unroll
+        for (int i = 0; i < NTM; ++i) ta[i] = lds_addr(sa) + tr_lane_offset<BM>(wm * (WR * 32) + i * 32, lane);
+      }
+      if constexpr (B_COL && !kM16) {
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) tb[j] = lds_addr(sb) + tr_lane_offset<BN>(wn * 64 + j * 32, lane);
+      }
 #pragma unroll
       for (int ks = 0; ks < KI; ++ks) {
 #pragma unroll
-        for (int j = 0; j < NTN; ++j)
-          fb[ks][j] = kM16 ? frag_load16<B_COL, BN>(sb, wn * 64 + j * 16, ks, lane) : frag_load<B_COL, BN>(sb, wn * 64 + j * 32, ks, lane);
+        for (int j = 0; j < NTN; ++j) {
+          if constexpr (kM16) fb[ks][j] = frag_load16<B_COL, BN>(sb, wn * 64 + j * 16, ks, lane);
+          else if constexpr (B_COL) fb[ks][j] = frag_load_tr<BN>(tb[j], ks);
+          else fb[ks][j] = frag_load<false, BN>(sb, wn * 64 + j * 32, ks, lane);
+        }
 #pragma unroll
-        for (int i = 0; i < NTM; ++i)
-          fa[ks][i] = kM16 ? frag_load16<A_COL, BM>(sa, wm * (WR * 32) + i * 16, ks, lane)
-                           : frag_load<A_COL, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
+        for (int i = 0; i < NTM; ++i) {
+          if constexpr (kM16) fa[ks][i] = frag_load16<A_COL, BM>(sa, wm * (WR * 32) + i * 16, ks, lane);
+          else if constexpr (A_COL) fa[ks][i] = frag_load_tr<BM>(ta[i], ks);
+          else fa[ks][i] = frag_load<false, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
+        }
         if constexpr (kInterleave) {
           if (fetch) {
 #pragma unroll
@@ -745,6 +809,7 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
       load_phase(sl_a, tf < nk, tf, t);
       sl_a = sl_a + 2 >= NSLOT ? sl_a + 2 - NSLOT : sl_a + 2;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      frag_fence(fa, fb);
       EVE_STAMP(1);
       __builtin_amdgcn_s_barrier();
       EVE_STAMP(2);
@@ -1043,16 +1108,35 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
       // ---- L phase
       const char* sa = smem + sl_c * kSub;
       const char* sb = smem + wrap(sl_c + 1) * kSub;
+      uint32_t ta[WR], tb[WTN];  // lane addresses of the transposed reads (asm reads, see frag_load_tr)
+      if constexpr (A_COL) {
+#pragma unroll
+        for (int i = 0; i < WR; ++i) ta[i] = lds_addr(sa) + tr_lane_offset<BM>(wm * (WR * 32) + i * 32, lane);
+      }
+      if constexpr (B_COL) {
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) tb[j] = lds_addr(sb) + tr_lane_offset<BN>(wn * 64 + j * 32, lane);
+      }
+      // without bias-gradient reads (plain loads that the compiler would make wait for the fetch) the fetch
+      // goes first: its issue and latency then overlap the fragment reads
+      if (!BIAS_GRAD && f_valid) fetch_next(wrap(sl_c + 3 + h));  // waves 0-3: B of the next step; waves 4-7: A of the one after
 #pragma unroll
       for (int ks = 0; ks < KI; ++ks) {
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) fb[ks][j] = frag_load<B_COL, BN>(sb, wn * 64 + j * 32, ks, lane);
+        for (int j = 0; j < WTN; ++j) {
+          if constexpr (B_COL) fb[ks][j] = frag_load_tr<BN>(tb[j], ks);
+          else fb[ks][j] = frag_load<false, BN>(sb, wn * 64 + j * 32, ks, lane);
+        }
 #pragma unroll
-        for (int i = 0; i < WR; ++i) fa[ks][i] = frag_load<A_COL, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
+        for (int i = 0; i < WR; ++i) {
+          if constexpr (A_COL) fa[ks][i] = frag_load_tr<BM>(ta[i], ks);
+          else fa[ks][i] = frag_load<false, BM>(sa, wm * (WR * 32) + i * 32, ks, lane);
+        }
       }
       if constexpr (BIAS_GRAD) {
         if (do_bias_grad) {
           // column sums of the k-major A tile: wave w owns 16-byte chunks 4w .. 4w+3 (32 columns), lane
+
           // (lane & 3) one chunk and (lane >> 2) every 16th k row; reduced inside the wave at the end
           const int chunk = 4 * wave + (lane & 3);
 #pragma unroll
@@ -1064,8 +1148,9 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
           }
         }
       }
-      if (f_valid) fetch_next(wrap(sl_c + 3 + h));  // waves 0-3: B of the next step; waves 4-7: A of the one after
+      if (BIAS_GRAD && f_valid) fetch_next(wrap(sl_c + 3 + h));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      frag_fence(fa, fb);
       __builtin_amdgcn_s_barrier();
       // ---- M phase
       __builtin_amdgcn_sched_barrier(0);
@@ -1288,7 +1373,9 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
 // the row extent is small enough that a larger tile would be mostly padding.
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
 static int launch(const MfmaDesc& d, int act, hipStream_t st) {
-  const bool small = !WGRAD && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024));
+  const char* force = getenv("EVE_FFN_TILE_ROWS");  // debug knob: force 128, 192 or 256
+  const bool small = !WGRAD && ((force && atoi(force) == 128) ||
+                                (!force && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024))));
   if (small) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
   if (!use_pingpong()) return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
   if constexpr (!A_COL && !WGRAD) {

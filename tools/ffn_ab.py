@@ -37,7 +37,7 @@ def run(variant, iters):
     os.environ["EVE_FFN_KERNEL"] = "lockstep" if variant == "lockstep" else "pingpong"
     os.environ.pop("EVE_FFN_TILE_ROWS", None)
     os.environ["EVE_FFN_PERSIST"] = "0" if variant == "onetile" else "1"  # onetile: one tile per workgroup
-    if variant in ("pp256", "pp192"):  # force the block-tile height of the ping-pong kernel
+    if variant in ("pp256", "pp192", "pp128"):  # force the block-tile height (128: the 4-wave lock-step kernel)
         os.environ["EVE_FFN_TILE_ROWS"] = variant[2:]
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf = tb = 0.0

@@ -12,7 +12,7 @@ def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     tot, n = collections.defaultdict(float), collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
-        m = re.search(r"grouped_gemm_(?:mfma|pp)<([^>]*)>", r["Kernel_Name"])
+        m = re.search(r"grouped_gemm_(?:mfma|ppp|pp_wgrad|pp)<([^>]*)>", r["Kernel_Name"])
         if not m or r["Counter_Name"] != counter:
             continue
         tot[m.group(1)] += float(r["Counter_Value"])

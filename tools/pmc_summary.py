@@ -4,7 +4,7 @@ f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    m = re.search(r"grouped_gemm_(?:mfma|pp)<([^>]*)>", n)
+    m = re.search(r"grouped_gemm_(?:mfma|ppp|pp_wgrad|pp)<([^>]*)>", n)
     if not m and len(sys.argv) < 3: continue
     key = "gemm<" + m.group(1) + ">" if m else re.sub(r"\(.*", "", n)[:60]
     agg[key][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[key].add(r["Dispatch_Id"])

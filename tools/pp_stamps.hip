@@ -26,7 +26,7 @@ static void run(const char* name, int G, int R, int N, int K, bool bcol, int sam
   hipMemset(bias, 0, (size_t)G * N * 2); hipMemset(Z, 0, nc * 2);
   MfmaDesc d{};
   d.G = G; d.E_local = G; d.rows = nullptr; d.Mext = R;
-  d.A = A; d.a_g = (long)R * K; d.lda = K;
+  d.A = A; d.a_g = (long)R * K; d.lda = A_COL ? R : K;
   d.B = B; d.b_g = (long)N * K; d.ldb = bcol ? N : K;
   d.C = C; d.C2 = C; d.c_g = (long)R * N; d.ldc = N; d.bias = bias; d.Zin = Z; d.N = N; d.K = K;
   d.dbg = nullptr; d.same_tile = same_tile;
@@ -63,5 +63,7 @@ int main() {
   run<false, false, MEPI_BIAS, false, false, 64>("fwd2  (row,row) N=768 K=3072, 256-row tiles", 32, 948, 768, 3072, false);
   run<false, false, MEPI_BIAS, false, false, 64, 3>("fwd2  (row,row) N=768 K=3072, 192-row tiles", 32, 948, 768, 3072, false);
   run<false, true, MEPI_STORE, false, false, 64, 3>("dgrad1 (row,col) N=768 K=3072, 192-row tiles", 32, 948, 768, 3072, true);
+  run<true, true, MEPI_STORE, true, false, 64>("wgrad (col,col) dw1: Mext=3072 N=768 K=948 rows, 64-deep", 32, 3072, 768, 948, true);
+  run<true, true, MEPI_STORE, true, false, 32>("wgrad (col,col) dw1: Mext=3072 N=768 K=948 rows, 32-deep", 32, 3072, 768, 948, true);
   return 0;
 }
