@@ -117,13 +117,40 @@ class _Bank:
             p.data = packed[e]  # same values, storage now inside the packed buffer
         return packed
 
-    def sync(self, experts: nn.ModuleList) -> None:
-        """(Re)pack when `.to()/.cuda()/.bfloat16()` or a foreign optimizer replaced storages."""
-        for kind, get in (("w1", lambda m: m.fc1.weight), ("b1", lambda m: m.fc1.bias),
-                          ("w2", lambda m: m.fc2.weight), ("b2", lambda m: m.fc2.bias)):
-            leaves = [get(m) for m in experts]
-            if not self._aliased(getattr(self, kind), leaves):
-                setattr(self, kind, self._pack(leaves))
+    _KINDS = (("w1", "fc1", "weight"), ("b1", "fc1", "bias"), ("w2", "fc2", "weight"), ("b2", "fc2", "bias"))
+
+    def leaves(self, experts) -> List[nn.Parameter]:
+        """The experts' Parameters in (expert, w1, b1, w2, b2) order.  The list is cached and re-validated per
+        call by identity through the modules' parameter dicts (a fraction of the cost of 4 * E attribute
+        look-ups through nn.Module.__getattr__, which dominated the host time of a step)."""
+        cached = getattr(self, "_leaves", None)
+        mods = experts._modules.values() if isinstance(experts, nn.Module) else experts
+        if cached is not None and len(cached) == 4 * len(mods):
+            ok, i = True, 0
+            for m in mods:
+                sub = m._modules
+                p1, p2 = sub["fc1"]._parameters, sub["fc2"]._parameters
+                if (p1["weight"] is not cached[i] or p1["bias"] is not cached[i + 1] or p2["weight"] is not cached[i + 2]
+                        or p2["bias"] is not cached[i + 3]):
+                    ok = False
+                    break
+                i += 4
+            if ok:
+                return cached
+        out: List[nn.Parameter] = []
+        for m in experts:
+            out += [m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+        self._leaves = out
+        return out
+
+    def sync(self, experts) -> List[nn.Parameter]:
+        """(Re)pack when `.to()/.cuda()/.bfloat16()` or a foreign optimizer replaced storages; returns leaves()."""
+        leaves = self.leaves(experts)
+        for k, (kind, _, _) in enumerate(self._KINDS):
+            mine = leaves[k::4]
+            if not self._aliased(getattr(self, kind), mine):
+                setattr(self, kind, self._pack(mine))
+        return leaves
 
 
 def _is_mlp(expert: nn.Module) -> bool:
@@ -178,10 +205,7 @@ class Experts(nn.Module):
 
     def packed_parameters(self, dtype: Optional[torch.dtype] = None):
         """(w1 [E_l,I,M], b1 [E_l,I], w2 [E_l,M,I], b2 [E_l,M]) wired into autograd."""
-        self._bank.sync(self.experts)
-        leaves = []
-        for m in self.experts:
-            leaves += [m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+        leaves = self._bank.sync(self.experts)
         w1, b1, w2, b2 = _PackedParamsFn.apply(self._bank, *leaves)
         if dtype is not None and w1.dtype != dtype:  # fp32 master weights, bf16 compute (autocast-style)
             w1, b1, w2, b2 = w1.to(dtype), b1.to(dtype), w2.to(dtype), b2.to(dtype)

@@ -92,10 +92,7 @@ class ModalitySplitFFN(nn.Module):
         xg = _SplitLNFn.apply(hidden_states, self.norm2_imag.weight, self.norm2_imag.bias, self.norm2_text.weight,
                               self.norm2_text.bias, n_vis, R, self.norm2_imag.eps)
         mlps = self._mlps()
-        self._bank.sync(mlps)  # the two MLPs' parameters alias one packed [2, ...] buffer per kind
-        leaves = []
-        for m in mlps:
-            leaves += [m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+        leaves = self._bank.sync(mlps)  # the two MLPs' parameters alias one packed [2, ...] buffer per kind
         w1, b1, w2, b2 = _PackedParamsFn.apply(self._bank, *leaves)
         dt = hidden_states.dtype
         if w1.dtype != dt:

@@ -26,3 +26,11 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"enqueue {1e3*(t1-t0)/K:.3f} ms/step   complete {1e3*(t2-t0)/K:.3f} ms/step")
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(K): step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
