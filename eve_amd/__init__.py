@@ -8,11 +8,14 @@ models/experts.py, models/multiway_transformer.py:44-55):
 All computation happens in hand-written HIP kernels (eve_amd/csrc, gfx950) reached through
 the C ABI of libeve_moe.so (include/eve_moe.h).
 """
+from .encoder import (Attention, MultiwayTransformerEncoder, MultiwayTransformerEncoderLayer,
+                      MultiwayTransformerEnocderLayer, eve_base_encoder)
 from .experts import ACT2FN, Experts, MultiwayTransformerMLP, QuickGELU
 from .graph import GraphedTrainStep
 from .layer import MoE
 from .multiway import ModalitySplitFFN
 from .sharded_moe import MOELayer, TopKGate, gumbel_rsample, top2gating
 
-__all__ = ["MoE", "GraphedTrainStep", "ModalitySplitFFN", "MOELayer", "TopKGate", "Experts", "MultiwayTransformerMLP", "QuickGELU", "ACT2FN",
+__all__ = ["Attention", "MultiwayTransformerEncoder", "MultiwayTransformerEncoderLayer", "MultiwayTransformerEnocderLayer",
+           "eve_base_encoder", "MoE", "GraphedTrainStep", "ModalitySplitFFN", "MOELayer", "TopKGate", "Experts", "MultiwayTransformerMLP", "QuickGELU", "ACT2FN",
            "gumbel_rsample", "top2gating"]
