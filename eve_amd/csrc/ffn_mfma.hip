@@ -365,6 +365,62 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
   }
 }
 
+// Epilogue of the plain-store launches on TRANSPOSED accumulators.  With the MFMA operands swapped
+// (D' = B A^T, i.e. C^T) a lane holds ROW l & 31 of a 32-row slab and, per 32-column tile j and register
+// group gq = r >> 2, the four CONSECUTIVE columns 8 gq + 4 (l >> 5) + (r & 3).  The finished values
+// (fp32 accumulator + fp32 bias, rounded once) are therefore staged as bf16 with one 8-byte LDS store per four
+// values into a row-major [32][64] image (pitch 136 B: the stores are conflict-free), and read back as 16-byte
+// row chunks for the same coalesced global stores as tile_epilogue: 8 ds_write_b64 + 8 ds_read_b64 per slab
+// instead of 32 ds_write_b32 + 8 ds_read_b128 through an fp32 image -- LDS stores move 64-85 B/clk, and the
+// fp32 image was most of the plain epilogue's time.  `img`: this wave's 4 352-byte staging area.
+constexpr int kImgPitch = 136;
+template <int EPI, int WR>
+__device__ __forceinline__ void tile_epilogue_t(const f32x16 (&acc)[WR][WTN], char* img, const MfmaDesc& d, int z, int e_out,
+                                                int m0, int n0, int mext, int wave, int lane) {
+  static_assert(EPI == MEPI_STORE || EPI == MEPI_BIAS, "plain epilogues only");
+  const int wm = wave >> 2, wn = wave & 3, c = lane & 31, hh = lane >> 5;
+  bf16_t* Cg = d.C + (size_t)z * d.c_g;
+  float bv[WTN][4][4];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      if constexpr (EPI == MEPI_BIAS) {
+        const uint2 b = *reinterpret_cast<const uint2*>(d.bias + (size_t)e_out * d.N + n0 + wn * 64 + j * 32 + 8 * gq + 4 * hh);
+        bv[j][gq][0] = bf16_bits_to_f32(b.x, 0); bv[j][gq][1] = bf16_bits_to_f32(b.x, 1);
+        bv[j][gq][2] = bf16_bits_to_f32(b.y, 0); bv[j][gq][3] = bf16_bits_to_f32(b.y, 1);
+      } else {
+        bv[j][gq][0] = bv[j][gq][1] = bv[j][gq][2] = bv[j][gq][3] = 0.f;
+      }
+    }
+  const int irow = lane >> 3, ich = lane & 7;
+  const int ncol = n0 + wn * 64 + ich * 8;
+  char* wr = img + c * kImgPitch + 8 * hh;
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const uint2 v = make_uint2(pack_bf16x2(acc[i][j][4 * gq] + bv[j][gq][0], acc[i][j][4 * gq + 1] + bv[j][gq][1]),
+                                   pack_bf16x2(acc[i][j][4 * gq + 2] + bv[j][gq][2], acc[i][j][4 * gq + 3] + bv[j][gq][3]));
+        *reinterpret_cast<uint2*>(wr + (j * 32 + 8 * gq) * 2) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + irow;
+      const int m = m0 + wm * (WR * 32) + i * 32 + row;
+      const uint2 lo = *reinterpret_cast<const uint2*>(img + row * kImgPitch + ich * 16);
+      const uint2 hi = *reinterpret_cast<const uint2*>(img + row * kImgPitch + ich * 16 + 8);
+      if (m < mext) *reinterpret_cast<uint4*>(Cg + (size_t)m * d.ldc + ncol) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Bias gradient of a weight-gradient tile: reduce the per-thread partial column sums of the k-major
 // A tiles (thread t owns the 8 columns of chunk t % (BM/8)) and store BM values.  Block-uniform call.
 template <int BM, int THREADS>
@@ -617,6 +673,8 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
   // which pack N = 768 problems on 256 CUs without a half-empty last wave of tiles.
   constexpr int BM = 64 * WR, KI = BKI / kKS, NSLOT = 5;
   constexpr int NTM = WR * 32 / kTR, NTN = 64 / kTR;  // MFMA tiles per wave
+  // plain-store epilogues run on transposed accumulators (MFMA operands swapped), see tile_epilogue_t
+  constexpr bool kT = !kM16 && (EPI == MEPI_STORE || EPI == MEPI_BIAS);
   static_assert(WR == 4 || (WR == 3 && !A_COL && !WGRAD), "192-row tiles: row-major A only");
   constexpr int kSub = 256 * BKI * 2;       // bytes of one ring slot (a 256 x BKI sub-tile)
   constexpr int NPB = kSub / 1024 / 4;      // DMA instructions per wave per B sub-tile
@@ -822,6 +880,7 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
 #pragma unroll
           for (int j = 0; j < NTN; ++j) {
             if constexpr (kM16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+            else if constexpr (kT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
           }
       __builtin_amdgcn_s_setprio(0);
@@ -840,7 +899,10 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
   { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 60 ? c_ : stamp_v; }
 #endif
   // split-K partials are indexed by (split, expert)
-  tile_epilogue<EPI, ACT, WR, kM16>(acc, smem, d, split * d.E_local + z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+  if constexpr (kT)
+    tile_epilogue_t<EPI, WR>(acc, smem + wave_u * 4352, d, split * d.E_local + z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+  else
+    tile_epilogue<EPI, ACT, WR, kM16>(acc, smem, d, split * d.E_local + z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
   if constexpr (BIAS_GRAD) {
     if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, split * d.E_local + z, m0);  // block-uniform
   }
@@ -974,7 +1036,10 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
   static_assert(!BIAS_GRAD || (A_COL && WR == 4), "bias gradient: k-major A tiles");
   constexpr int kSub = 256 * BKI * 2;
   constexpr int kRing = NSLOT * kSub;
+  // plain-store epilogues run on transposed accumulators (MFMA operands swapped), see tile_epilogue_t
+  constexpr bool kT = EPI == MEPI_STORE || EPI == MEPI_BIAS;
   constexpr int kStageWave = 16 * EPI_LD * 4;
+  static_assert(kStageWave >= 32 * kImgPitch, "tile_epilogue_t's bf16 slab image fits the staging area");
   constexpr bool kStageInRing = kRing + 8 * kStageWave > 160 * 1024;
   constexpr int NPB = kSub / 1024 / 4;
   constexpr int NPA = BM * BKI * 2 / 1024 / 4;
@@ -1161,7 +1226,8 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
         for (int i = 0; i < WR; ++i)
 #pragma unroll
           for (int j = 0; j < WTN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = kT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my fetch has landed (it had the whole M phase)
@@ -1185,8 +1251,12 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
           *reinterpret_cast<uint4*>(Cg + (size_t)m * d.ldc + cur.n0 + wn * 64 + (lane & 7) * 8) = make_uint4(0, 0, 0, 0);
       }
     } else {
-      tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0, cur.n0, cur.mext,
-                                       wave, lane);
+      if constexpr (kT)
+        tile_epilogue_t<EPI, WR>(acc, reinterpret_cast<char*>(ep), d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0,
+                                 cur.n0, cur.mext, wave, lane);
+      else
+        tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0, cur.n0, cur.mext,
+                                         wave, lane);
     }
     if constexpr (BIAS_GRAD) {
       if (do_bias_grad) {
