@@ -1041,6 +1041,14 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
   constexpr int kStageWave = 16 * EPI_LD * 4;
   static_assert(kStageWave >= 32 * kImgPitch, "tile_epilogue_t's bf16 slab image fits the staging area");
   constexpr bool kStageInRing = kRing + 8 * kStageWave > 160 * 1024;
+  // Long (activation) epilogues: the two halves' E phases must overlap each other -- one after the other, as the
+  // plain schedule runs them, would cost a whole extra epilogue per tile.  Waves 4-7 therefore go from their last
+  // M phase straight into E (no barrier in between) and spend one empty phase after it, which restores their
+  // one-phase lag.  Both halves then stage at the same time: waves 0-3 in ring slot sl_c + 4, waves 4-7 in slot
+  // sl_c + 3 (free until waves 0-3 fetch into it in the next tile's first L phase, which starts after the barrier
+  // that ends both E phases).
+  constexpr bool kResync = EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT;
+  static_assert(!kResync || !WGRAD, "resynchronised E phases: forward / dgrad launches (every tile has K steps)");
   constexpr int NPB = kSub / 1024 / 4;
   constexpr int NPA = BM * BKI * 2 / 1024 / 4;
   constexpr int NP = NPB;
@@ -1231,13 +1239,13 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my fetch has landed (it had the whole M phase)
-      __builtin_amdgcn_s_barrier();
+      if (!(kResync && h == 1 && t == cur.nk - 1)) __builtin_amdgcn_s_barrier();
       sl_c = wrap(sl_c + 2);
     }
     // ---- E phase
     // (behind the ring every wave has its own image: after a tile without K steps -- an expert that
     // received no rows -- waves 0-3 are in their next E phase while waves 4-7 are still in this one)
-    float* ep = reinterpret_cast<float*>(kStageInRing ? smem + wrap(sl_c + 4) * kSub + w4 * kStageWave
+    float* ep = reinterpret_cast<float*>(kStageInRing ? smem + wrap(sl_c + 4 - (kResync ? h : 0)) * kSub + w4 * kStageWave
                                                       : smem + kRing + wave_u * kStageWave);
     if (WGRAD && cur.nk == 0) {
       // An expert that received no rows: its gradient tile is zero.  Stored straight from registers -- after
@@ -1285,10 +1293,11 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my staging image is free again
     // waves 4-7 run one phase behind: their last E phase has no partner phase and no barrier
     if (!have) {
-      if (h == 0) __builtin_amdgcn_s_barrier();
+      if (h == 0 && !kResync) __builtin_amdgcn_s_barrier();
       break;
     }
     __builtin_amdgcn_s_barrier();
+    if (kResync && h == 1) __builtin_amdgcn_s_barrier();  // the empty phase: waves 0-3 are in the next tile's first L phase
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -1385,11 +1394,12 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   pr.d[1] = d2 ? *d2 : d;
   pr.n0 = blocks(d);
   pr.ntotal = pr.n0 + (d2 ? blocks(*d2) : 0);
-  // persistent variant: one workgroup per CU walks the tiles (single K segment only)
-  // (not for the activation epilogues: their E phases are long and VALU-heavy, and run one half after the
-  // other here, where the one-tile kernel overlaps the two halves' epilogues -- measured 4-6 % slower)
-  const bool persist = use_persistent() && EPI != MEPI_BIAS_ACT && EPI != MEPI_DACT && EPI != MEPI_STORE_F32 &&
-                       (!WGRAD || d.G == d.E_local) && pr.ntotal > cu_count();
+  // persistent variant: one workgroup per CU walks the tiles (single K segment only).  The activation
+  // epilogues run it with resynchronised E phases (kResync; EVE_FFN_PERSIST_ACT=0 selects the one-tile kernel
+  // for A/B timing: the persistent one measured 2 % faster on those launches).
+  const bool act_epi = EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT;
+  const bool persist = use_persistent() && (!act_epi || !getenv("EVE_FFN_PERSIST_ACT") || getenv("EVE_FFN_PERSIST_ACT")[0] != '0') &&
+                       EPI != MEPI_STORE_F32 && (!WGRAD || d.G == d.E_local) && pr.ntotal > cu_count();
   constexpr int kStage = 8 * 16 * EPI_LD * 4;
   constexpr int kLdsP = (5 * 256 * BKI * 2 + kStage > 160 * 1024) ? 5 * 256 * BKI * 2 : 5 * 256 * BKI * 2 + kStage;
   dim3 grid(persist ? (cu_count() / 8) * 8 : pr.ntotal);

@@ -60,6 +60,8 @@ static void run(const char* name, int G, int R, int N, int K, bool bcol, int sam
 }
 
 int main() {
+  run<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1  (row,row) N=3072 K=768, bias + quick_gelu epilogue", 32, 948, 3072, 768, false);
+  run<false, true, MEPI_DACT, false, false, 64>("dgrad2 (row,col) N=3072 K=768, act' epilogue", 32, 948, 3072, 768, true);
   run<false, false, MEPI_BIAS, false, false, 64>("fwd2  (row,row) N=768 K=3072, 256-row tiles", 32, 948, 768, 3072, false);
   run<false, false, MEPI_BIAS, false, false, 64, 3>("fwd2  (row,row) N=768 K=3072, 192-row tiles", 32, 948, 768, 3072, false);
   run<false, true, MEPI_STORE, false, false, 64, 3>("dgrad1 (row,col) N=768 K=3072, 192-row tiles", 32, 948, 768, 3072, true);
