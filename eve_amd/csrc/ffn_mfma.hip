@@ -1369,17 +1369,33 @@ static int cu_count() {
   return n;
 }
 
-// Debug knob for A/B timing: EVE_FFN_KERNEL=lockstep selects the older 256-row kernel.
-static bool use_pingpong() {
-  const char* v = getenv("EVE_FFN_KERNEL");
-  return !(v && v[0] == 'l');
+// Debug knobs for A/B timing, read from the environment once per process:
+//   EVE_FFN_KERNEL=lockstep    the older lock-step 256-row kernel instead of the ping-pong kernels
+//   EVE_FFN_PERSIST=0          one tile per workgroup instead of the persistent kernel
+//   EVE_FFN_PERSIST_ACT=0      ... for the activation-epilogue launches only
+//   EVE_FFN_TILE_ROWS=128|192|256   force the block-tile height of the forward / dgrad launches
+//   EVE_FFN_KSPLIT=n           force the weight-gradient split-K factor
+//   EVE_FFN_WGRAD32=1          32-deep persistent weight-gradient kernel for all tiles
+struct Knobs {
+  bool pingpong, persist, persist_act, wgrad32;
+  int tile_rows, ksplit;
+};
+static const Knobs& knobs() {
+  static const Knobs k = [] {
+    auto env = [](const char* n) { return getenv(n); };
+    Knobs q;
+    q.pingpong = !(env("EVE_FFN_KERNEL") && env("EVE_FFN_KERNEL")[0] == 'l');
+    q.persist = !(env("EVE_FFN_PERSIST") && env("EVE_FFN_PERSIST")[0] == '0');
+    q.persist_act = !(env("EVE_FFN_PERSIST_ACT") && env("EVE_FFN_PERSIST_ACT")[0] == '0');
+    q.wgrad32 = env("EVE_FFN_WGRAD32") != nullptr;
+    q.tile_rows = env("EVE_FFN_TILE_ROWS") ? atoi(env("EVE_FFN_TILE_ROWS")) : 0;
+    q.ksplit = env("EVE_FFN_KSPLIT") ? atoi(env("EVE_FFN_KSPLIT")) : 0;
+    return q;
+  }();
+  return k;
 }
-
-// EVE_FFN_PERSIST=0 selects the one-tile-per-workgroup ping-pong kernel.
-static bool use_persistent() {
-  const char* v = getenv("EVE_FFN_PERSIST");
-  return !(v && v[0] == '0');
-}
+static bool use_pingpong() { return knobs().pingpong; }
+static bool use_persistent() { return knobs().persist; }
 
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI, int WR = 4>
 static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc* d2 = nullptr) {
@@ -1398,7 +1414,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   // epilogues run it with resynchronised E phases (kResync; EVE_FFN_PERSIST_ACT=0 selects the one-tile kernel
   // for A/B timing: the persistent one measured 2 % faster on those launches).
   const bool act_epi = EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT;
-  const bool persist = use_persistent() && (!act_epi || !getenv("EVE_FFN_PERSIST_ACT") || getenv("EVE_FFN_PERSIST_ACT")[0] != '0') &&
+  const bool persist = use_persistent() && (!act_epi || knobs().persist_act) &&
                        EPI != MEPI_STORE_F32 && (!WGRAD || d.G == d.E_local) && pr.ntotal > cu_count();
   constexpr int kStage = 8 * 16 * EPI_LD * 4;
   constexpr int kLdsP = (5 * 256 * BKI * 2 + kStage > 160 * 1024) ? 5 * 256 * BKI * 2 : 5 * 256 * BKI * 2 + kStage;
@@ -1453,17 +1469,16 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
 // the row extent is small enough that a larger tile would be mostly padding.
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
 static int launch(const MfmaDesc& d, int act, hipStream_t st) {
-  const char* force = getenv("EVE_FFN_TILE_ROWS");  // debug knob: force 128, 192 or 256
-  const bool small = !WGRAD && ((force && atoi(force) == 128) ||
+  const int force = knobs().tile_rows;  // debug knob: force 128, 192 or 256
+  const bool small = !WGRAD && (force == 128 ||
                                 (!force && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024))));
   if (small) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
   if (!use_pingpong()) return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
   if constexpr (!A_COL && !WGRAD) {
-    const char* v = getenv("EVE_FFN_TILE_ROWS");  // debug knob: force 192 or 256
     const long cus = cu_count(), per = (long)d.G * (d.N / BN);
     const long cost256 = ceil_div(per * ceil_div(d.Mext, 256), cus) * 256;
     const long cost192 = ceil_div(per * ceil_div(d.Mext, 192), cus) * 192;
-    const bool use192 = v ? atoi(v) == 192 : cost192 * 10 < cost256 * 9;
+    const bool use192 = force ? force == 192 : cost192 * 10 < cost256 * 9;
     if (use192) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, 64, 3>(d, act, st);
   }
   return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, (A_COL && B_COL) ? 32 : 64>(d, act, st);
@@ -1517,7 +1532,7 @@ static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st
 static int wgrad_ksplit(int G, int E_local, int M, int I) {
   const long tiles = 2L * E_local * (M / 256) * (I / 256);  // both GEMMs share a launch
   const long cus = cu_count();
-  if (getenv("EVE_FFN_KSPLIT")) return max(1, atoi(getenv("EVE_FFN_KSPLIT")));  // debug knob
+  if (knobs().ksplit > 0) return knobs().ksplit;  // debug knob
   if (tiles >= 2 * cus) return 1;
   int j = 1;
   while (j < 8 && tiles * j < 4 * cus) j *= 2;
@@ -1586,7 +1601,7 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
       EVE_CHECK_LAUNCH("wgrad_reduce_kernel");
       return EVE_OK;
     }
-    if (!getenv("EVE_FFN_WGRAD32")) return launch_pp_wgrad<MEPI_STORE>(d, d1, st);  // one launch for both GEMMs
+    if (!knobs().wgrad32) return launch_pp_wgrad<MEPI_STORE>(d, d1, st);  // one launch for both GEMMs
     return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, &d1);  // debug knob: all tiles 32 deep (persistent)
   }
   if (int rc = launch<true, true, MEPI_STORE, true, true>(d, act, st)) return rc;

@@ -1,5 +1,5 @@
-"""A/B timing of the two 256-row grouped-GEMM kernels (EVE_FFN_KERNEL=lockstep|pingpong) in ONE process,
-interleaved, so that device-to-device and clock differences cancel; also checks that they agree."""
+"""A/B timing of the grouped-GEMM kernel variants (EVE_FFN_KERNEL / EVE_FFN_PERSIST / EVE_FFN_TILE_ROWS knobs), one child
+process per variant on the same device (the library reads the knobs once per process)."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,14 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--fill", type=float, default=1.0)
 ap.add_argument("--variants", default="lockstep,pingpong")
 a = ap.parse_args()
+if "," in a.variants:  # the library reads its debug knobs once per process: one child process per variant
+    import subprocess
+    for v in a.variants.split(","):
+        rc = subprocess.run([sys.executable, os.path.abspath(__file__)] + [x for x in sys.argv[1:] if not x.startswith("--variants")
+                                                                         and x != a.variants] + ["--variants", v]).returncode
+        if rc:
+            sys.exit(rc)
+    sys.exit(0)
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 bf = torch.bfloat16
