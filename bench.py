@@ -101,10 +101,18 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    # EVE_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo (the all-to-all goes through host memory), to run the
+    # N > 1 code path on a one-GPU box.  Its numbers mean nothing and the line says so.
+    rehearsal = os.environ.get("EVE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from eve_amd import ops
 
@@ -182,7 +190,7 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         tpath = os.path.join(REPO, "profiles", "r01_gemm_traffic.json")
-        if args.dtype == "bf16" and args.model == "base" and B == 64 and os.path.exists(tpath):
+        if world == 1 and args.dtype == "bf16" and args.model == "base" and B == 64 and os.path.exists(tpath):
             # HBM bytes per launch from separate rocprofv3 --pmc passes of this workload (FETCH_SIZE doubled as the
             # gfx950 guide prescribes, WRITE_SIZE); counters cannot be read live from inside the process
             traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
@@ -207,6 +215,8 @@ def main():
             "roofline": roofline,
             "phases_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }
+        if rehearsal:
+            line["rehearsal"] = "all ranks on cuda:0 over gloo with a host-staged exchange: NOT a measurement"
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, M, I, E, n_vis, T)
         print(json.dumps(line), flush=True)

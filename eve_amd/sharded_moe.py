@@ -118,12 +118,21 @@ def _mode_code(mode: Optional[str], has_embed: bool) -> int:
 # ------------------------------------------------------------------ autograd functions
 class _AllToAll(torch.autograd.Function):
     """Equal-split all-to-all over the expert-parallel group (RCCL on MI355X); its backward
-    is the same exchange applied to the gradient (reference sharded_moe.py:84-100)."""
+    is the same exchange applied to the gradient (reference sharded_moe.py:84-100).
+
+    A gloo group has no all-to-all for GPU tensors: there the rows are exchanged through host memory.  That is
+    how the expert-parallel path is rehearsed with several ranks on ONE GPU (tests/test_ep_gpu.py,
+    `EVE_BENCH_REHEARSAL=1 ... bench.py --gpus 2`); the compute stays on the GPU either way."""
 
     @staticmethod
     def forward(ctx: Any, group, input: Tensor) -> Tensor:  # type: ignore[override]
         ctx.group = group
         input = input.contiguous()
+        if input.is_cuda and dist.get_backend(group) == "gloo":
+            host_in = input.cpu()
+            host_out = torch.empty_like(host_in)
+            dist.all_to_all_single(host_out, host_in, group=group)
+            return host_out.to(input.device)
         output = torch.empty_like(input)
         dist.all_to_all_single(output, input, group=group)
         return output
