@@ -251,8 +251,9 @@ def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True):
     return z, a, y
 
 
-def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int):
-    """-> (dx [G,R,M], dw1, db1, dw2, db2) with the shapes / dtype of the forward operands."""
+def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int, grads_out=None):
+    """-> (dx [G,R,M], dw1, db1, dw2, db2) with the shapes / dtype of the forward operands.
+    `grads_out` = (dw1, db1, dw2, db2) to write the parameter gradients into caller-provided tensors."""
     for t, n in ((dy, "dy"), (x, "x"), (z, "z"), (a, "a"), (w1, "w1"), (w2, "w2")):
         _chk(t, n, x.dtype)
     G, R, M = x.shape
@@ -260,10 +261,16 @@ def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int):
     dev = x.device
     dz = torch.empty(G, R, I, dtype=x.dtype, device=dev)
     dx = torch.empty(G, R, M, dtype=x.dtype, device=dev)  # rows >= rows[g] stay unwritten and are never read
-    dw1 = torch.empty(E_l, I, M, dtype=x.dtype, device=dev)
-    db1 = torch.empty(E_l, I, dtype=x.dtype, device=dev)
-    dw2 = torch.empty(E_l, M, I, dtype=x.dtype, device=dev)
-    db2 = torch.empty(E_l, M, dtype=x.dtype, device=dev)
+    if grads_out is not None:
+        dw1, db1, dw2, db2 = grads_out
+        for t, n, shp in ((dw1, "dw1", (E_l, I, M)), (db1, "db1", (E_l, I)), (dw2, "dw2", (E_l, M, I)), (db2, "db2", (E_l, M))):
+            _chk(t, n, x.dtype)
+            assert tuple(t.shape) == shp, (n, tuple(t.shape), shp)
+    else:
+        dw1 = torch.empty(E_l, I, M, dtype=x.dtype, device=dev)
+        db1 = torch.empty(E_l, I, dtype=x.dtype, device=dev)
+        dw2 = torch.empty(E_l, M, I, dtype=x.dtype, device=dev)
+        db2 = torch.empty(E_l, M, dtype=x.dtype, device=dev)
     nbytes = _lib.load().eve_ffn_bwd_workspace_bytes(G, E_l, R, M, I, _dt(x))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     PROFILE.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),

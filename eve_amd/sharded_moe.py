@@ -142,6 +142,114 @@ class _AllToAll(torch.autograd.Function):
         return None, _AllToAll.apply(ctx.group, grad_output)
 
 
+class _Done:
+    """A finished exchange (the host-staged gloo path is synchronous)."""
+
+    def wait(self):
+        return True
+
+
+def _exchange_views(group, send, recv):
+    """Peer p gets `send[p]` and `recv[p]` is filled from peer p; every tensor is a contiguous view.  Returns a
+    work handle: `wait()` makes the current stream wait for the exchange, which runs on RCCL's own stream -- so
+    kernels launched on the current stream in the meantime overlap it."""
+    if send[0].is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one GPU: through host memory
+        host_in = torch.stack([t.cpu() for t in send])
+        host_out = torch.empty_like(host_in)
+        dist.all_to_all_single(host_out, host_in, group=group)
+        for p, t in enumerate(recv):
+            t.copy_(host_out[p])
+        return _Done()
+    return dist.all_to_all(recv, send, group=group, async_op=True)
+
+
+def ep_chunks(e_local: int) -> int:
+    """Pieces the local experts are cut into for the pipelined exchange (EVE_EP_CHUNKS overrides; 1 = one
+    exchange each way around one FFN launch sequence, as `_AllToAll` + `Experts.forward` do it)."""
+    import os
+    v = os.environ.get("EVE_EP_CHUNKS")
+    n = int(v) if v else 2
+    n = max(1, min(n, e_local))
+    while e_local % n:
+        n -= 1
+    return n
+
+
+class _EPPipelineFn(torch.autograd.Function):
+    """Expert-parallel exchange -> expert FFNs -> exchange back, pipelined over chunks of the local experts:
+    all chunks' dispatch exchanges are posted at once, the FFN of chunk c starts when its rows have arrived
+    and runs beside the exchange of chunk c+1, and its result travels back beside the FFN of chunk c+1.  xGMI
+    moves the rows (point-to-point links, RCCL's own stream) while the CUs compute; only the first chunk's way
+    in and the last chunk's way out are exposed.  Backward is the same pipeline on the gradients.  Same
+    arithmetic per row as the unchunked path (the FFN kernels work per expert group), same `[ep, E_local, C, M]`
+    layout on both sides (reference sharded_moe.py:368-379)."""
+
+    @staticmethod
+    def forward(ctx, group, nch, act, xd4, w1, b1, w2, b2):  # type: ignore[override]
+        ep, e_l, C, M = xd4.shape
+        xd4 = xd4.contiguous()
+        step = e_l // nch
+        need_grad = any(ctx.needs_input_grad[3:])
+        out4 = torch.empty_like(xd4)
+        recv, works = [], []
+        for c in range(nch):
+            lo = c * step
+            buf = torch.empty(ep, step, C, M, dtype=xd4.dtype, device=xd4.device)
+            works.append(_exchange_views(group, [xd4[p, lo:lo + step] for p in range(ep)], [buf[p] for p in range(ep)]))
+            recv.append(buf)
+        saved, back, keep = [], [], []
+        for c in range(nch):
+            lo = c * step
+            works[c].wait()
+            x = recv[c].view(ep * step, C, M)
+            z, a, y = ops.ffn_fwd(x, w1[lo:lo + step], b1[lo:lo + step], w2[lo:lo + step], b2[lo:lo + step], None, act,
+                                  save_z=need_grad)
+            y4 = y.view(ep, step, C, M)
+            back.append(_exchange_views(group, [y4[p] for p in range(ep)], [out4[p, lo:lo + step] for p in range(ep)]))
+            keep.append(y)
+            saved += [x, z, a]
+        for w in back:
+            w.wait()
+        if need_grad:
+            ctx.save_for_backward(w1, w2, *saved)
+            ctx.group, ctx.nch, ctx.act = group, nch, act
+        return out4
+
+    @staticmethod
+    def backward(ctx, dout4):  # type: ignore[override]
+        w1, w2, *saved = ctx.saved_tensors
+        group, nch, act = ctx.group, ctx.nch, ctx.act
+        dout4 = dout4.contiguous()
+        ep, e_l, C, M = dout4.shape
+        step = e_l // nch
+        I = w1.shape[1]
+        dev, dt = dout4.device, dout4.dtype
+        recv, works = [], []
+        for c in range(nch):
+            lo = c * step
+            buf = torch.empty(ep, step, C, M, dtype=dt, device=dev)
+            works.append(_exchange_views(group, [dout4[p, lo:lo + step] for p in range(ep)], [buf[p] for p in range(ep)]))
+            recv.append(buf)
+        dxd4 = torch.empty_like(dout4)
+        dw1 = torch.empty(e_l, I, M, dtype=dt, device=dev)
+        db1 = torch.empty(e_l, I, dtype=dt, device=dev)
+        dw2 = torch.empty(e_l, M, I, dtype=dt, device=dev)
+        db2 = torch.empty(e_l, M, dtype=dt, device=dev)
+        back, keep = [], []
+        for c in range(nch):
+            lo = c * step
+            x, z, a = saved[3 * c:3 * c + 3]
+            works[c].wait()
+            dx, *_ = ops.ffn_bwd(recv[c].view(ep * step, C, M), x, z, a, w1[lo:lo + step], w2[lo:lo + step], None, act,
+                                 grads_out=(dw1[lo:lo + step], db1[lo:lo + step], dw2[lo:lo + step], db2[lo:lo + step]))
+            dx4 = dx.view(ep, step, C, M)
+            back.append(_exchange_views(group, [dx4[p] for p in range(ep)], [dxd4[p, lo:lo + step] for p in range(ep)]))
+            keep.append(dx)
+        for w in back:
+            w.wait()
+        return None, None, None, dxd4, dw1, db1, dw2, db2
+
+
 class _GateFn(torch.autograd.Function):
     """logits, noise -> (weight [S,2], l_aux) + index tensors; HIP eve_gate_top2_fwd/bwd."""
 
@@ -429,6 +537,14 @@ class MOELayer(nn.Module):
         C = xd.shape[0] // E
 
         group = self._resolve_ep_group()
+        if group is not None and getattr(self.experts, "packed_parameters", None) is not None:
+            nch = ep_chunks(self.num_local_experts)
+            if nch > 1:  # pipelined exchange / FFN / exchange over chunks of the local experts
+                w1, b1, w2, b2 = self.experts.packed_parameters(xd.dtype)
+                expert_output = _EPPipelineFn.apply(group, nch, self.experts._act_code,
+                                                    xd.view(self.ep_size, self.num_local_experts, C, M), w1, b1, w2, b2)
+                out = _CombineFn.apply(expert_output.view(-1, M), weight, slot, slot_token, slot_weight)
+                return out.view(orig_shape)
         if group is not None:
             xd = _AllToAll.apply(group, xd.view(self.ep_size, -1)).view(-1, M)
             rows = None  # peers' fill counts are not exchanged: every capacity row is processed
