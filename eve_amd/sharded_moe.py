@@ -149,6 +149,22 @@ class _Done:
         return True
 
 
+_list_exchange_ok = True
+
+
+class _PackedWork:
+    """all_to_all_single on packed copies; `wait()` unpacks into the receive views."""
+
+    def __init__(self, work, packed_in, packed_out, recv):
+        self.work, self.packed_in, self.packed_out, self.recv = work, packed_in, packed_out, recv
+
+    def wait(self):
+        self.work.wait()
+        for p, t in enumerate(self.recv):
+            t.copy_(self.packed_out[p])
+        return True
+
+
 def _exchange_views(group, send, recv):
     """Peer p gets `send[p]` and `recv[p]` is filled from peer p; every tensor is a contiguous view.  Returns a
     work handle: `wait()` makes the current stream wait for the exchange, which runs on RCCL's own stream -- so
@@ -160,7 +176,17 @@ def _exchange_views(group, send, recv):
         for p, t in enumerate(recv):
             t.copy_(host_out[p])
         return _Done()
-    return dist.all_to_all(recv, send, group=group, async_op=True)
+    global _list_exchange_ok
+    if _list_exchange_ok:
+        try:
+            return dist.all_to_all(recv, send, group=group, async_op=True)
+        except (RuntimeError, NotImplementedError) as exc:  # a backend without the list form: pack and say so
+            import warnings
+            warnings.warn(f"eve_amd: all_to_all on tensor lists failed ({exc}); exchanging packed copies instead")
+            _list_exchange_ok = False
+    packed_in = torch.stack(send)
+    packed_out = torch.empty_like(packed_in)
+    return _PackedWork(dist.all_to_all_single(packed_out, packed_in, group=group, async_op=True), packed_in, packed_out, recv)
 
 
 def ep_chunks(e_local: int) -> int:

@@ -85,6 +85,16 @@ def _worker(rank, world, port, q):
             tot = g if tot is None else [a + b for a, b in zip(tot, g)]
         for got, ref in zip((w1.grad, b1.grad, w2.grad, b2.grad), tot):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=5e-6)
+        # the pipelined path's per-peer exchange; gloo has no list all_to_all, so this runs its packed-copy form
+        import warnings
+        from eve_amd.sharded_moe import _exchange_views
+        send = [torch.full((3, 4), float(rank * 10 + peer)) for peer in range(world)]
+        buf = torch.empty(world, 3, 4)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _exchange_views(dist.group.WORLD, send, [buf[peer] for peer in range(world)]).wait()
+        for peer in range(world):
+            assert torch.all(buf[peer] == float(peer * 10 + rank))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
