@@ -180,9 +180,11 @@ def main():
     # kept assignments of the last step (exact K for the algorithmic flop count)
     kept = int((moe.moe.last_slot >= 0).sum().item())
     ffn_ms = prof.get("eve_ffn_fwd", (0.0, 0))[0] + prof.get("eve_ffn_bwd", (0.0, 0))[0]
-    # Per step: 6 grouped GEMMs of 2*M*I*K flops each in 5 launches (the two weight-gradient GEMMs share one).
-    launches = 5 * args.steps
-    flops_per_launch = 6.0 / 5.0 * 2.0 * M * I * kept
+    # Per step: 6 grouped GEMMs of 2*M*I*K flops each; an eve_ffn_fwd call is 2 launches, an eve_ffn_bwd call 3 (the
+    # two weight-gradient GEMMs share one): 5 launches per step on one GPU, 5 per expert chunk with expert parallelism
+    # (there K counts rank 0's own kept assignments; the rows its experts receive from all ranks are about as many).
+    launches = 2 * prof.get("eve_ffn_fwd", (0.0, 0))[1] + 3 * prof.get("eve_ffn_bwd", (0.0, 0))[1]
+    flops_per_launch = 6.0 * 2.0 * M * I * kept * args.steps / max(launches, 1)
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
     roofline = None
     if ffn_ms > 0:
@@ -197,7 +199,7 @@ def main():
             traffic_src = "profiles/r01_gemm_traffic.json"
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "grouped expert-FFN GEMM (eve::grouped_gemm_pp, 5 launches/step computing 6 GEMMs)",
+                    "kernel": f"grouped expert-FFN GEMM (eve::grouped_gemm_pp, {launches // max(args.steps, 1)} launches/step computing 6 GEMMs)",
                     "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch,
                     "timing": "HIP events on the launch stream around eve_ffn_fwd / eve_ffn_bwd over the K steps"}
 

@@ -246,6 +246,8 @@ extern "C" int eve_ffn_fwd(const void* x, const void* w1, const void* b1, const 
   return ffn_fwd_generic<float>(x, w1, b1, w2, b2, z, a, y, rows, G, E_local, R, M, I, act, st);
 }
 
+extern "C" int eve_ffn_set_shared_gpu(int shared) { return ffn_set_shared_gpu(shared); }
+
 extern "C" size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype) {
   (void)R;
   if (G <= 0 || E_local <= 0 || G % E_local != 0 || dtype != EVE_BF16 || !ffn_mfma_supported(M, I)) return 0;

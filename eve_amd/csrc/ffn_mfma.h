@@ -16,4 +16,7 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
 // bytes of scratch ffn_bwd_mfma needs for these shapes (0 when the weight gradients are not split along K)
 size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int M, int I);
 
+// launch policy (eve_ffn_set_shared_gpu); returns the previous setting
+int ffn_set_shared_gpu(int shared);
+
 }  // namespace eve

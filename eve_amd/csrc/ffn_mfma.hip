@@ -17,6 +17,7 @@
 // epilogue goes through LDS (fp32) so that global stores are 16 bytes per lane along rows, and
 // fuses bias, activation, activation derivative and -- in the weight-gradient kernels -- the
 // bias gradient (column sums of the k-major A tile).
+#include <atomic>
 #include "ffn_mfma.h"
 
 #include <cstdlib>
@@ -1394,8 +1395,10 @@ static const Knobs& knobs() {
   }();
   return k;
 }
+static std::atomic<int> g_shared_gpu{0};  // eve_ffn_set_shared_gpu
+int ffn_set_shared_gpu(int shared) { return g_shared_gpu.exchange(shared ? 1 : 0); }
 static bool use_pingpong() { return knobs().pingpong; }
-static bool use_persistent() { return knobs().persist; }
+static bool use_persistent() { return knobs().persist && !g_shared_gpu.load(std::memory_order_relaxed); }
 
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI, int WR = 4>
 static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc* d2 = nullptr) {

@@ -251,6 +251,19 @@ def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True):
     return z, a, y
 
 
+class shared_gpu:
+    """`with ops.shared_gpu():` -- FFN launches issued inside leave room for other kernels (RCCL exchanges) on
+    the GPU: one workgroup per tile instead of persistent workgroups (eve_ffn_set_shared_gpu)."""
+
+    def __enter__(self):
+        self.prev = _lib.load().eve_ffn_set_shared_gpu(1)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().eve_ffn_set_shared_gpu(self.prev)
+        return False
+
+
 def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int, grads_out=None):
     """-> (dx [G,R,M], dw1, db1, dw2, db2) with the shapes / dtype of the forward operands.
     `grads_out` = (dw1, db1, dw2, db2) to write the parameter gradients into caller-provided tensors."""

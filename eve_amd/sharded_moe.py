@@ -228,8 +228,9 @@ class _EPPipelineFn(torch.autograd.Function):
             lo = c * step
             works[c].wait()
             x = recv[c].view(ep * step, C, M)
-            z, a, y = ops.ffn_fwd(x, w1[lo:lo + step], b1[lo:lo + step], w2[lo:lo + step], b2[lo:lo + step], None, act,
-                                  save_z=need_grad)
+            with ops.shared_gpu():  # RCCL's kernels hold CUs beside these launches
+                z, a, y = ops.ffn_fwd(x, w1[lo:lo + step], b1[lo:lo + step], w2[lo:lo + step], b2[lo:lo + step], None,
+                                      act, save_z=need_grad)
             y4 = y.view(ep, step, C, M)
             back.append(_exchange_views(group, [y4[p] for p in range(ep)], [out4[p, lo:lo + step] for p in range(ep)]))
             keep.append(y)
@@ -266,8 +267,10 @@ class _EPPipelineFn(torch.autograd.Function):
             lo = c * step
             x, z, a = saved[3 * c:3 * c + 3]
             works[c].wait()
-            dx, *_ = ops.ffn_bwd(recv[c].view(ep * step, C, M), x, z, a, w1[lo:lo + step], w2[lo:lo + step], None, act,
-                                 grads_out=(dw1[lo:lo + step], db1[lo:lo + step], dw2[lo:lo + step], db2[lo:lo + step]))
+            with ops.shared_gpu():
+                dx, *_ = ops.ffn_bwd(recv[c].view(ep * step, C, M), x, z, a, w1[lo:lo + step], w2[lo:lo + step], None,
+                                     act, grads_out=(dw1[lo:lo + step], db1[lo:lo + step], dw2[lo:lo + step],
+                                                     db2[lo:lo + step]))
             dx4 = dx.view(ep, step, C, M)
             back.append(_exchange_views(group, [dx4[p] for p in range(ep)], [dxd4[p, lo:lo + step] for p in range(ep)]))
             keep.append(dx)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 3
+#define EVE_MOE_ABI_VERSION 4
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -186,6 +186,15 @@ int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, con
  * weight-gradient GEMMs are split along K -- few local experts (expert parallelism, the two-group modality
  * split) leave too few output tiles for the CUs; the slices' fp32 partials are then summed in a fixed order. */
 size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype);
+
+/* Process-wide launch policy of eve_ffn_fwd / eve_ffn_bwd (no counterpart in the reference, whose experts are
+ * stock GEMM calls).  shared != 0: the caller runs other work -- RCCL exchanges of the pipelined expert-parallel
+ * path -- on the GPU beside the GEMMs, so the launches use one workgroup per output tile, which the dispatcher
+ * places on whichever CUs are free; shared == 0 (default): forward / dgrad launches are persistent, one workgroup
+ * per CU walking the tiles, which assumes the whole chip (a CU held by another kernel would push its workgroup
+ * into a second round and double the launch).  Takes effect for launches issued after the call; returns the
+ * previous setting.  Results are identical either way. */
+int eve_ffn_set_shared_gpu(int shared);
 
 /* ------------------------------------------------- hard modality split of the non-MoE layers
  * Reference models/multiway_transformer.py:366-370: vision positions [:, :n_vis] go through

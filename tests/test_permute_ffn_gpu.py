@@ -135,6 +135,34 @@ def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
         assert err < (2e-2 if dtype == torch.bfloat16 else 2e-5), (name, err)
 
 
+def test_ffn_shared_gpu_launch_policy_gives_identical_results():
+    """eve_ffn_set_shared_gpu(1): one workgroup per tile instead of persistent workgroups (the pipelined
+    expert-parallel path runs RCCL beside the GEMMs) -- same arithmetic per tile, bit-equal results."""
+    from eve_amd import ops, _lib
+    G, E_l, R, M, I = 32, 16, 300, 768, 3072  # 768 / 192 forward tiles: more than the 256 CUs, so the default is persistent
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16).to(DEV)
+    x, dy = mk(G, R, M), mk(G, R, M)
+    w1, b1, w2, b2 = mk(E_l, I, M, s=M ** -0.5), mk(E_l, I, s=0.1), mk(E_l, M, I, s=I ** -0.5), mk(E_l, M, s=0.1)
+    rows = torch.randint(100, R + 1, (G,), generator=g, dtype=torch.int32).to(DEV)
+
+    def run():
+        z, a, y = ops.ffn_fwd(x, w1, b1, w2, b2, rows, ops.ACTS["quick_gelu"])
+        return (y, a) + tuple(ops.ffn_bwd(dy, x, z, a, w1, w2, rows, ops.ACTS["quick_gelu"]))
+
+    base = run()
+    assert _lib.load().eve_ffn_set_shared_gpu(0) == 0
+    with ops.shared_gpu():
+        shared = run()
+        assert _lib.load().eve_ffn_set_shared_gpu(1) == 1
+    assert _lib.load().eve_ffn_set_shared_gpu(0) == 0  # restored
+    valid = (torch.arange(R, device=DEV)[None, :, None] < rows[:, None, None])
+    for k, (p, q) in enumerate(zip(base, shared)):
+        if p.dim() == 3 and p.shape[0] == G:  # rows beyond rows[g] are left unwritten
+            p, q = torch.where(valid, p, 0), torch.where(valid, q, 0)
+        assert torch.equal(p, q), k
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,T,n_vis,M,E,mode", [(3, 37, 5, 64, 8, "vl"), (4, 237, 197, 768, 32, "vl"),
                                                   (2, 33, 0, 256, 32, "text"), (2, 50, 7, 128, 5, "vision"),
