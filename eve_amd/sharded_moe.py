@@ -191,10 +191,13 @@ def _exchange_views(group, send, recv):
 
 def ep_chunks(e_local: int) -> int:
     """Pieces the local experts are cut into for the pipelined exchange (EVE_EP_CHUNKS overrides; 1 = one
-    exchange each way around one FFN launch sequence, as `_AllToAll` + `Experts.forward` do it)."""
+    exchange each way around one FFN launch sequence, as `_AllToAll` + `Experts.forward` do it).  Two chunks
+    while a chunk keeps at least 4 experts: the weight-gradient GEMMs of a chunk have E_chunk x 72 output tiles
+    and measured (cfg-2 dims, one GPU, `tools/ffn_only.py`) +0.10 ms per step for 2 x 8 experts but +0.29 ms
+    for 2 x 2, more than half of the exchange time that pipelining can hide at ep = 8."""
     import os
     v = os.environ.get("EVE_EP_CHUNKS")
-    n = int(v) if v else 2
+    n = int(v) if v else (2 if e_local >= 8 else 1)
     n = max(1, min(n, e_local))
     while e_local % n:
         n -= 1
