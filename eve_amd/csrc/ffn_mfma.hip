@@ -1531,14 +1531,17 @@ static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st
 
 // Weight-gradient split-K factor: with few local experts (expert parallelism, the two-group modality split) the
 // two dW GEMMs have too few 256 x 256 tiles for the CUs, each with a very long K loop; the K range is then cut
-// into `ksplit` slices (whole segments first, then row slices) with fp32 partials and a reduction pass.
+// into `ksplit` slices (whole segments first, then row slices) with fp32 partials and a reduction pass.  The
+// partials cost HBM traffic (j x the weights' size in fp32, written and read), so the factor is the smallest that
+// gives every CU a tile: measured at the cfg-2 dims (tools/ffn_only.py, EVE_FFN_KSPLIT), 1 expert: 0.39 / 0.28 /
+// 0.25 / 0.26 ms backward for j = 1 / 2 / 4 / 8; 2 experts: 0.51 / 0.40 / 0.41 / 0.48; 4 experts: 0.69 / 0.71 /
+// 0.75 / 0.86.
 static int wgrad_ksplit(int G, int E_local, int M, int I) {
   const long tiles = 2L * E_local * (M / 256) * (I / 256);  // both GEMMs share a launch
   const long cus = cu_count();
   if (knobs().ksplit > 0) return knobs().ksplit;  // debug knob
-  if (tiles >= 2 * cus) return 1;
   int j = 1;
-  while (j < 8 && tiles * j < 4 * cus) j *= 2;
+  while (j < 8 && tiles * j < cus) j *= 2;
   const int nseg = G / E_local;
   if ((nseg & (nseg - 1)) != 0) return j <= nseg && nseg % j == 0 ? j : 1;  // odd segment counts: whole-segment splits only
   return j;
