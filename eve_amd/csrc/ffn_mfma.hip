@@ -257,9 +257,18 @@ __device__ __forceinline__ void frag_fence(bf16x8 (&fa)[KI][NA], bf16x8 (&fb)[KI
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t w, int hi) {
   return __uint_as_float(hi ? (w & 0xffff0000u) : (w << 16));
 }
+// accumulator + bias where the epilogue has one ("x + 0.f" is not a no-op to the compiler: it is -0's sign)
+template <int EPI> __device__ __forceinline__ float add_bias(float a, float b) {
+  if constexpr (EPI == MEPI_BIAS || EPI == MEPI_BIAS_ACT) return a + b;
+  else return a;
+}
+// one v_cvt_pk_bf16_f32 (round to nearest even); written as a vector conversion so that the compiler does not pair
+// the scalar conversions its own way and then shuffle 16-bit halves back into place
+typedef __attribute__((ext_vector_type(2))) float pk_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 pk_bf16x2;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  const bf16_t a = static_cast<bf16_t>(lo), b = static_cast<bf16_t>(hi);
-  return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+  const pk_f32x2 t = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(t, pk_bf16x2));
 }
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
@@ -320,7 +329,7 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
 #pragma unroll
         for (int j = 0; j < NTN; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ep[(ii * 16 + g4 + r) * EPI_LD + j * 16 + c] = acc[2 * i + ii][j][r] + bv[j];
+          for (int r = 0; r < 4; ++r) ep[(ii * 16 + g4 + r) * EPI_LD + j * 16 + c] = add_bias<EPI>(acc[2 * i + ii][j][r], bv[j]);
     } else {
       const int c = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -328,7 +337,7 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-          ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
+          ep[row * EPI_LD + j * 32 + c] = add_bias<EPI>(acc[i][j][r], bv[j]);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -403,8 +412,10 @@ __device__ __forceinline__ void tile_epilogue_t(const f32x16 (&acc)[WR][WTN], ch
     for (int j = 0; j < WTN; ++j)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const uint2 v = make_uint2(pack_bf16x2(acc[i][j][4 * gq] + bv[j][gq][0], acc[i][j][4 * gq + 1] + bv[j][gq][1]),
-                                   pack_bf16x2(acc[i][j][4 * gq + 2] + bv[j][gq][2], acc[i][j][4 * gq + 3] + bv[j][gq][3]));
+        const uint2 v = make_uint2(pack_bf16x2(add_bias<EPI>(acc[i][j][4 * gq], bv[j][gq][0]),
+                                               add_bias<EPI>(acc[i][j][4 * gq + 1], bv[j][gq][1])),
+                                   pack_bf16x2(add_bias<EPI>(acc[i][j][4 * gq + 2], bv[j][gq][2]),
+                                               add_bias<EPI>(acc[i][j][4 * gq + 3], bv[j][gq][3])));
         *reinterpret_cast<uint2*>(wr + (j * 32 + 8 * gq) * 2) = v;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -998,7 +1009,7 @@ __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN],
       for (int rr = 0; rr < 8; ++rr) {
         const int r = hv * 8 + rr;
         const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh;
-        ep[row * EPI_LD + j * 32 + c] = acc[i][j][r] + bv[j];
+        ep[row * EPI_LD + j * 32 + c] = add_bias<EPI>(acc[i][j][r], bv[j]);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
