@@ -192,9 +192,11 @@ def _exchange_views(group, send, recv):
 def ep_chunks(e_local: int) -> int:
     """Pieces the local experts are cut into for the pipelined exchange (EVE_EP_CHUNKS overrides; 1 = one
     exchange each way around one FFN launch sequence, as `_AllToAll` + `Experts.forward` do it).  Two chunks
-    while a chunk keeps at least 4 experts: the weight-gradient GEMMs of a chunk have E_chunk x 72 output tiles
-    and measured (cfg-2 dims, one GPU, `tools/ffn_only.py`) +0.10 ms per step for 2 x 8 experts but +0.29 ms
-    for 2 x 2, more than half of the exchange time that pipelining can hide at ep = 8."""
+    while a chunk keeps at least 4 experts.  Smaller GEMM launches cost time: measured at the cfg-2 dims on one
+    GPU (`tools/ffn_only.py`), two half launch sequences against one take +0.10 ms per step at 2 x 8 experts
+    (ep 2), +0.13 ms at 2 x 4 (ep 4) and +0.14 ms at 2 x 2 (ep 8), and twice as many collectives are launched;
+    pipelining hides about half of the exchange time, estimated 0.6 / 0.36 / 0.2-0.3 ms per step at ep 2 / 4 / 8
+    -- a clear gain up to ep 4, break-even at ep 8, which therefore keeps the plain sequence."""
     import os
     v = os.environ.get("EVE_EP_CHUNKS")
     n = int(v) if v else (2 if e_local >= 8 else 1)
