@@ -51,6 +51,7 @@ template <> struct Vec16<float> {
   float4 raw;
   __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
   __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = v; }
+  __device__ __forceinline__ void set_all(const float (&v)[4]) { raw = make_float4(v[0], v[1], v[2], v[3]); }
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
@@ -65,6 +66,18 @@ template <> struct Vec16<bf16_t> {
     uint32_t h = (uint32_t)__builtin_bit_cast(unsigned short, b);
     uint32_t& w = (&raw.x)[i >> 1];
     w = (i & 1) ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
+  }
+  // all eight at once: one v_cvt_pk_bf16_f32 per pair (element-wise set() costs four merge ops per value)
+  __device__ __forceinline__ void set_all(const float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    uint32_t w[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const f2 t = {v[2 * p], v[2 * p + 1]};
+      w[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, b2));
+    }
+    raw = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };
 

@@ -798,8 +798,10 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
         xa[u] = load16<T>(hp + k);
         if constexpr (EMB) {
           const Vec16<T> ev = load16<T>(emb + k);
+          float xs[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xa[u].set(j, xa[u].get(j) + ev.get(j));
+          for (int j = 0; j < 8; ++j) xs[j] = xa[u].get(j) + ev.get(j);
+          xa[u].set_all(xs);
         }
         const float m = (k0 + 16 * u < k_hi) ? wmask : 0.f;
         const float4 w0 = *reinterpret_cast<const float4*>(wp + k), w1 = *reinterpret_cast<const float4*>(wp + k + 4);

@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void split_ln_fwd_kernel(const T* __restrict__
       if (c < chunks) {
         const Vec16<T> gv = load16<T>(g + c * N), bv = load16<T>(be + c * N);
         Vec16<T> o;
+        float ov[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) o.set(j, (x[k][j] - mean) * rstd * gv.get(j) + bv.get(j));
+        for (int j = 0; j < N; ++j) ov[j] = (x[k][j] - mean) * rstd * gv.get(j) + bv.get(j);
+        o.set_all(ov);
         store16<T>(dst + c * N, o);
       }
     }
@@ -130,12 +132,14 @@ __global__ __launch_bounds__(256) void split_ln_bwd_kernel(const T* __restrict__
       const int c = lane + 64 * k;
       if (c < chunks) {
         Vec16<T> o;
+        float ov[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-          o.set(j, rstd * (gg[k][j] - c1 - xh[k][j] * c2));
+          ov[j] = rstd * (gg[k][j] - c1 - xh[k][j] * c2);
           if (text) { ag[1][k][j] += dy[k][j] * xh[k][j]; ab[1][k][j] += dy[k][j]; }
           else { ag[0][k][j] += dy[k][j] * xh[k][j]; ab[0][k][j] += dy[k][j]; }
         }
+        o.set_all(ov);
         store16<T>(dh + (size_t)s * M + c * N, o);
       }
     }

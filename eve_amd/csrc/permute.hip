@@ -31,8 +31,10 @@ __global__ __launch_bounds__(256) void dispatch_fwd_kernel(const T* __restrict__
       Vec16<T> v = load16<T>(src + c * N);
       if (emb) {
         const Vec16<T> e = load16<T>(emb + c * N);
+        float xs[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) v.set(j, v.get(j) + e.get(j));
+        for (int j = 0; j < N; ++j) xs[j] = v.get(j) + e.get(j);
+        v.set_all(xs);
       }
       store16<T>(dst + c * N, v);
     }
@@ -104,8 +106,7 @@ __global__ __launch_bounds__(128) void dispatch_bwd_kernel(const T* __restrict__
     for (int t = 0; t < kDbTok; ++t) {
       if (t >= ntok) continue;
       Vec16<T> o;
-#pragma unroll
-      for (int j = 0; j < N; ++j) o.set(j, acc[t][j]);
+      o.set_all(acc[t]);
       store16<T>(dh + (size_t)(s0 + t) * M + c * N, o);
     }
   }
@@ -139,8 +140,7 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(const T* __restrict__ 
         for (int j = 0; j < N; ++j) acc[j] = fmaf(w2, v.get(j), acc[j]);
       }
       Vec16<T> o;
-#pragma unroll
-      for (int j = 0; j < N; ++j) o.set(j, acc[j]);
+      o.set_all(acc);
       store16<T>(out + (size_t)s * M + c * N, o);
     }
   }
@@ -177,14 +177,17 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(const T* __restrict__ 
       const Vec16<T> v1 = load16<T>(y1 + c * N);  // unconditional (row 0 when there is no slot): loads stay in flight together
       const Vec16<T> v2 = load16<T>(y2 + c * N);
       Vec16<T> o1, o2;
+      float p1[N], p2[N];
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         const float dj = d.get(j);
         a1 = fmaf(dj, v1.get(j), a1);
         a2 = fmaf(dj, v2.get(j), a2);
-        o1.set(j, w1 * dj);
-        o2.set(j, w2 * dj);
+        p1[j] = w1 * dj;
+        p2[j] = w2 * dj;
       }
+      o1.set_all(p1);
+      o2.set_all(p2);
       if (s1 >= 0) store16<T>(dy + (size_t)s1 * M + c * N, o1);
       if (s2 >= 0) store16<T>(dy + (size_t)s2 * M + c * N, o2);
     }
@@ -398,11 +401,10 @@ __global__ __launch_bounds__(kRbThreads) void route_bwd_kernel(const T* __restri
     const int s = s0 + t;
     float* g = G + t * ld + c * N;
     Vec16<T> o;
+    float ov[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const float v = (g[j] + (s1 >= 0 ? v1.get(j) : 0.f)) + (s2 >= 0 ? v2.get(j) : 0.f);
-      o.set(j, v);
-    }
+    for (int j = 0; j < N; ++j) ov[j] = (g[j] + (s1 >= 0 ? v1.get(j) : 0.f)) + (s2 >= 0 ? v2.get(j) : 0.f);
+    o.set_all(ov);
 #pragma unroll
     for (int j = 0; j < N; ++j) g[j] = s < S ? o.get(j) : 0.f;
     if (s < S) store16<T>(dh + (size_t)s * M + c0 + c * N, o);
