@@ -4,7 +4,7 @@
     python tools/isa_hist.py eve_amd/csrc/gate.hip gate_wgrad_bf16_kernelILb1E
 
 Compiles the file with the build's flags to assembly (`--cuda-device-only -S`, cached under /tmp by source
-mtime), cuts the first kernel whose mangled name contains the given substring at its `s_endpgm`, and counts
+mtime), cuts the first kernel whose mangled name contains the given substring at its `.Lfunc_end` label, and counts
 opcodes -- over the whole body, or only behind the last MFMA (the E phase of the GEMM kernels).  This is how
 the four-op shuffle around every scalar bf16 conversion in the activation epilogue was found.
 """
@@ -30,7 +30,7 @@ starts = [i for i, l in enumerate(lines) if l.startswith("_Z") and sub in l and 
 if not starts:
     raise SystemExit(f"no kernel whose name contains {sub!r} in {asm}")
 a = starts[0]
-e = next(i for i in range(a, len(lines)) if "s_endpgm" in lines[i])
+e = next(i for i in range(a, len(lines)) if lines[i].startswith(".Lfunc_end"))  # not the first s_endpgm: early exits
 body = lines[a + 1:e]
 if tail_only:
     last = max(i for i, l in enumerate(body) if "v_mfma" in l)
