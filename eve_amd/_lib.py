@@ -29,6 +29,7 @@ SIGNATURES = {
     "eve_gate_logits_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eve_gate_workspace_bytes": (c_size_t, [_I, _I]),
     "eve_gate_top2_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "eve_gate_top2_fwd_noalloc": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "eve_gumbel_from_uniform": (c_int, [_P, _P, c_long, _P]),
     "eve_gate_top2_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "eve_gate_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),

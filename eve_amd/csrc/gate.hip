@@ -2,6 +2,8 @@
 // ordered per-expert queue positions, capacity drop, renormalised weights, l_aux), and
 // their backward.  gfx950, wave64.  Reference semantics: models/sharded_moe.py:172-235,
 // :283-297, :350-364 (see include/eve_moe.h for the per-entry-point citations).
+#include <mutex>
+
 #include "common.h"
 
 namespace eve {
@@ -1179,26 +1181,17 @@ extern "C" size_t eve_gate_workspace_bytes(int S, int E) {
   return gate_ws_layout(S, E).total;
 }
 
-extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C, float* gates,
-                                 int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
-                                 float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
-  EVE_REQUIRE(logits && noise && gates && idx && loc && slot && weight && slot_token && slot_weight && exp_counts &&
-                  rows && l_aux && workspace,
-              EVE_ERR_ARG, "eve_gate_top2_fwd: null pointer");
-  EVE_REQUIRE(S > 0 && E > 0 && C > 0, EVE_ERR_ARG, "eve_gate_top2_fwd: bad shape S=%d E=%d C=%d", S, E, C);
-  EVE_REQUIRE(E <= 1024, EVE_ERR_UNSUPPORTED, "eve_gate_top2_fwd: E=%d > 1024", E);
-  EVE_REQUIRE((long long)E * C < (1ll << 31), EVE_ERR_ARG, "eve_gate_top2_fwd: E*C overflows int32");
-  const GateWs w = gate_ws_layout(S, E);
-  EVE_REQUIRE(workspace_bytes >= w.total, EVE_ERR_WORKSPACE, "eve_gate_top2_fwd: workspace %zu < %zu", workspace_bytes, w.total);
-  EVE_REQUIRE(((uintptr_t)workspace & 255) == 0, EVE_ERR_ARG, "eve_gate_top2_fwd: workspace must be 256-byte aligned");
-  char* ws = static_cast<char*>(workspace);
+// Launch sequence of the fused gate; `ws` is device scratch laid out by gate_ws_layout (every word of it is
+// written before it is read, so its previous contents never matter).
+static int gate_top2_launch(const float* logits, const float* noise, int noise_is_uniform, int S, int E,
+                            int C, float* gates, int32_t* idx, int32_t* loc, int32_t* slot, float* weight,
+                            int32_t* slot_token, float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux,
+                            char* ws, const GateWs& w, hipStream_t st) {
   int32_t* hist = reinterpret_cast<int32_t*>(ws + w.hist);
   int32_t* boff = reinterpret_cast<int32_t*>(ws + w.boff);
   int32_t* rank = reinterpret_cast<int32_t*>(ws + w.rank);
   float* gsum = reinterpret_cast<float*>(ws + w.gsum);
   int32_t* tot = reinterpret_cast<int32_t*>(ws + w.tot);
-  hipStream_t st = S_(stream);
   const int fused_assign = E <= 32 && w.nblk <= kAssign32MaxBlocks ? 1 : 0;
   if (E <= 32) {
     if (E == 32)
@@ -1229,6 +1222,78 @@ extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int no
                      loc, slot, weight, slot_token, slot_weight);
   EVE_CHECK_LAUNCH("gate_assign_kernel");
   return EVE_OK;
+}
+
+#define EVE_GATE_TOP2_CHECK_ARGS(who)                                                                                  \
+  EVE_REQUIRE(logits && noise && gates && idx && loc && slot && weight && slot_token && slot_weight && exp_counts &&  \
+                  rows && l_aux,                                                                                       \
+              EVE_ERR_ARG, who ": null pointer");                                                                      \
+  EVE_REQUIRE(S > 0 && E > 0 && C > 0, EVE_ERR_ARG, who ": bad shape S=%d E=%d C=%d", S, E, C);                        \
+  EVE_REQUIRE(E <= 1024, EVE_ERR_UNSUPPORTED, who ": E=%d > 1024", E);                                                 \
+  EVE_REQUIRE((long long)E * C < (1ll << 31), EVE_ERR_ARG, who ": E*C overflows int32")
+
+extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C, float* gates,
+                                 int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
+                                 float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  EVE_GATE_TOP2_CHECK_ARGS("eve_gate_top2_fwd");
+  EVE_REQUIRE(workspace, EVE_ERR_ARG, "eve_gate_top2_fwd: null workspace");
+  const GateWs w = gate_ws_layout(S, E);
+  EVE_REQUIRE(workspace_bytes >= w.total, EVE_ERR_WORKSPACE, "eve_gate_top2_fwd: workspace %zu < %zu", workspace_bytes, w.total);
+  EVE_REQUIRE(((uintptr_t)workspace & 255) == 0, EVE_ERR_ARG, "eve_gate_top2_fwd: workspace must be 256-byte aligned");
+  return gate_top2_launch(logits, noise, noise_is_uniform, S, E, C, gates, idx, loc, slot, weight,
+                          slot_token, slot_weight, exp_counts, rows, l_aux, static_cast<char*>(workspace), w, S_(stream));
+}
+
+// ---- the same gate for callers that cannot allocate (include/eve_moe.h: eve_gate_top2_fwd_noalloc) ------------
+// The scratch of the gate kernels lives in the code object instead of in caller memory.  Every GPU the library
+// runs on holds its own copy of this array at its own address until the process ends; `scratch` in host code
+// is only the symbol's host-side stand-in, never a device address: the address is looked up once per device
+// (that device current) and only the looked-up pointer is handed to kernels.
+static __device__ __align__(256) unsigned char scratch[EVE_GATE_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices];  // per device, filled on the first call with that device current
+
+int gate_scratch_for_current_device(char** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    set_error("eve_gate_top2_fwd_noalloc: hipGetDevice failed or device %d out of range: %s", dev, hipGetErrorString(e));
+    return EVE_ERR_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      set_error("eve_gate_top2_fwd_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+      return EVE_ERR_LAUNCH;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = static_cast<char*>(g_scratch_ptr[dev]);
+  return EVE_OK;
+}
+}  // namespace
+
+extern "C" int eve_gate_top2_fwd_noalloc(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C,
+                                         float* gates, int32_t* idx, int32_t* loc, int32_t* slot, float* weight,
+                                         int32_t* slot_token, float* slot_weight, int64_t* exp_counts, int32_t* rows,
+                                         float* l_aux, void* stream) {
+  EVE_GATE_TOP2_CHECK_ARGS("eve_gate_top2_fwd_noalloc");
+  const GateWs w = gate_ws_layout(S, E);
+  EVE_REQUIRE(w.total <= (size_t)EVE_GATE_NOALLOC_SCRATCH_BYTES, EVE_ERR_WORKSPACE,
+              "eve_gate_top2_fwd_noalloc: S=%d tokens x E=%d experts need %zu bytes of scratch, the built-in buffer holds %zu; "
+              "use eve_gate_top2_fwd with a caller workspace",
+              S, E, w.total, (size_t)EVE_GATE_NOALLOC_SCRATCH_BYTES);
+  char* ws = nullptr;
+  const int rc = gate_scratch_for_current_device(&ws);
+  if (rc != EVE_OK) return rc;
+  return gate_top2_launch(logits, noise, noise_is_uniform, S, E, C, gates, idx, loc, slot,
+                          weight, slot_token, slot_weight, exp_counts, rows, l_aux, ws, w, S_(stream));
 }
 
 extern "C" int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const int32_t* loc, const float* d_weight,

@@ -97,6 +97,24 @@ int eve_gate_top2_fwd(const float* logits, const float* noise, int noise_is_unif
                       int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* eve_gate_top2_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference; it exists only for
+ * those callers.  Same inputs, outputs, kernels and results as eve_gate_top2_fwd, but the gate's scratch
+ * (block histograms, in-block ranks, per-block gate sums) lives in a buffer of
+ * EVE_GATE_NOALLOC_SCRATCH_BYTES built into the library's code object instead of a caller workspace; the
+ * call performs no hipMalloc / hipFree and no allocating library routine.  Each GPU the library runs on
+ * holds its own copy of that buffer until the process ends; its address is looked up on the first call on
+ * a device (make that call outside graph capture).  Shapes whose eve_gate_workspace_bytes(S, E) exceeds the
+ * buffer (about S > 110 000 tokens at E = 32) are rejected with EVE_ERR_WORKSPACE.  All calls on one GPU
+ * share the buffer: calls that overlap on one GPU (different streams or threads) race; calls on one stream
+ * are ordered and safe.  Nothing in the buffer has to start at zero (every word is written before it is
+ * read within a call). */
+#define EVE_GATE_NOALLOC_SCRATCH_BYTES (2u << 20)
+int eve_gate_top2_fwd_noalloc(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C,
+                              float* gates, int32_t* idx, int32_t* loc, int32_t* slot, float* weight,
+                              int32_t* slot_token, float* slot_weight, int64_t* exp_counts, int32_t* rows,
+                              float* l_aux, void* stream);
+
 /* noise[i] = Gumbel(0,1) variate of the standard-uniform draw uniform[i] in [0,1): the arithmetic of
  * torch.distributions.Gumbel(0,1).rsample -- low + u*(high-low) with low = tiny, high = 1-eps, then
  * -log(-log(.)), each step rounded to fp32 -- that the reference's gumbel_rsample performs
