@@ -1,20 +1,27 @@
 """bench.py -- MoE-layer forward+backward tokens/s on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 without WORLD_SIZE in the environment: starts N worker processes
+        itself (one per GPU, RCCL, rendezvous on 127.0.0.1) and prints rank 0's line.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W        (the same workers under torchrun)
 
 A step is one forward + backward of ONE EVE-Base modality-aware MoE layer over one synthetic
 image+text token batch (BASELINE.json configs[1] layer shape: B=64 per GPU, 197 vision + 40
 text tokens, M=768, I=3072, 32 experts, top-2, bf16), inputs resident in HBM.  With N > 1 the
 32 experts are sharded over the N ranks (expert parallel, RCCL all-to-all) and every rank
 brings its own batch (weak scaling).  Rank 0 prints ONE JSON line.
+
+On one GPU the line also carries `other_configs` (the other BASELINE.json layer shapes and the full 12-layer
+EVE-Base encoder step, a few timed steps each) and `cpu_baseline`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,66 +46,254 @@ def parse():
     ap.add_argument("--model", default="base", choices=["base", "large"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3/4/5 and 12-layer encoder entries")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------ N > 1 launcher
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE: start the N ranks as child processes.  Nothing in this
+    parent has touched the GPU (importing torch and counting devices do not initialise HIP), the children are
+    fresh interpreters, and the parent only waits and passes rank 0's output through."""
+    n = args.gpus
+    rehearsal = os.environ.get("EVE_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if not rehearsal and have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) visible (EVE_BENCH_REHEARSAL=1 runs all ranks on "
+                         "cuda:0 over gloo as a functional rehearsal, not a measurement)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1) // 2)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    deadline = time.time() + 1500
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:  # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        if time.time() > deadline:
+            for q in alive:
+                q.kill()
+            return 124
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ workload
 def build_layer(M, I, E, ep, rank, n_vis, dtype, dev):
+    """One modality-aware MoE layer with independent experts, initialised on the GPU."""
     import eve_amd
     torch.manual_seed(1234)  # replicated parameters (gate, modality embeddings) identical on all ranks
     moe = eve_amd.MoE(M, eve_amd.MultiwayTransformerMLP("quick_gelu", M, I), num_experts=E, ep_size=ep, k=2,
                       num_tokens=n_vis)
     with torch.no_grad():
         torch.nn.init.trunc_normal_(moe.moe.gate.wg.weight, std=0.02, a=-0.02, b=0.02)
+    moe = moe.to(dtype).to(dev)
+    with torch.no_grad():
         e_local = E // ep
-        for j, ex in enumerate(moe.moe.experts.experts):  # independent experts
-            g = torch.Generator().manual_seed(1000 + rank * e_local + j)
+        for j, ex in enumerate(moe.moe.experts.experts):
+            g = torch.Generator(device=dev).manual_seed(1000 + rank * e_local + j)
             for lin in (ex.fc1, ex.fc2):
-                torch.nn.init.trunc_normal_(lin.weight, std=0.02, a=-0.02, b=0.02, generator=g)
+                w = torch.empty(lin.weight.shape, dtype=torch.float32, device=dev)
+                torch.nn.init.trunc_normal_(w, std=0.02, a=-0.02, b=0.02, generator=g)
+                lin.weight.copy_(w)
                 lin.bias.zero_()
-    return moe.to(dtype).to(dev)
+    # exp_counts as an asynchronous pinned copy (opt-in; the default is the reference's blocking .to('cpu')):
+    # a timed step must not contain a host synchronisation per layer
+    moe.moe.blocking_exp_counts = False
+    return moe
+
+
+def synth_batch(B, T, M, dtype, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    h = torch.nn.functional.layer_norm(torch.randn(B, T, M, generator=g), (M,)).to(dtype).to(dev)
+    dout = torch.randn(B, T, M, generator=g).to(dtype).to(dev)
+    return h, dout
 
 
 def cpu_baseline(args, M, I, E, n_vis, T):
     """The oracle's dense one-hot port of the reference algorithm (what models/sharded_moe.py +
-    models/experts.py execute), fp32 PyTorch on the host cores, fwd+bwd, on a bounded sample."""
+    models/experts.py execute), fp32 PyTorch on the host cores, fwd+bwd, on a bounded sample.  The experts'
+    parameters are separate leaf tensors, as the reference's ModuleList of nn.Linear (models/experts.py:12-16):
+    with stacked leaves the backward of every `w1[e]` select materialises a full [E,I,M] zero tensor."""
     from oracle import moe_oracle as orc  # CPU baseline leg only
     B = 8
     cores = torch.get_num_threads()
-    p = {k: v.requires_grad_(True) for k, v in orc.make_params(M, I, E, seed=1234).items()}
+    raw = orc.make_params(M, I, E, seed=1234)
+    p = {k: ([t.clone().requires_grad_(True) for t in v] if k in ("w1", "b1", "w2", "b2")
+             else v.clone().requires_grad_(True)) for k, v in raw.items()}
+    leaves = [t for v in p.values() for t in (v if isinstance(v, list) else [v])]
     h = orc.synth_hidden(B, T, M, seed=7)
     g = torch.Generator().manual_seed(8)
     noise = orc.gumbel_noise((B * T, E), generator=g)
+    fwd_s = bwd_s = 0.0
 
-    def step():
-        for v in p.values():
+    def step(timed):
+        nonlocal fwd_s, bwd_s
+        for v in leaves:
             v.grad = None
         hh = h.clone().requires_grad_(True)
+        t0 = time.perf_counter()
         out, l_aux, _ = orc.dense_moe_forward(hh, p, noise, mode="vl", n_vis=n_vis)
+        t1 = time.perf_counter()
         (out.sum() + l_aux).backward()
+        t2 = time.perf_counter()
+        if timed:
+            fwd_s += t1 - t0
+            bwd_s += t2 - t1
 
-    step()
-    step()
+    step(False)
+    step(False)
     n, t0 = 0, time.perf_counter()
     while True:
-        step()
+        step(True)
         n += 1
         el = time.perf_counter() - t0
         if (n >= 5 and el >= args.cpu_baseline_seconds) or n >= 200:
             break
     return {"value": round(B * T * n / el, 1), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "fwd_ms": round(fwd_s / n * 1e3, 1), "bwd_ms": round(bwd_s / n * 1e3, 1),
             "sample": f"B={B} of the {args.batch} sequences (S={B * T} tokens, EVE-{args.model} layer dims), fp32 dense "
-                      f"one-hot/einsum port of the reference algorithm, fwd+bwd, 2 warm-up + {n} timed iterations"}
+                      f"one-hot/einsum port of the reference algorithm with per-expert leaf parameters, fwd+bwd, "
+                      f"2 warm-up + {n} timed iterations"}
+
+
+def time_layer(moe, h, dout, steps, warmup, train=True):
+    """ms per eager step of `moe` on (h, dout); train: fwd+bwd, else eval forward under no_grad."""
+    params = list(moe.parameters())
+    if train:
+        moe.train()
+
+        def step():
+            for p in params:
+                p.grad = None
+            x = h.detach().requires_grad_(True)
+            out, l_aux, _ = moe(x, mode="vl")
+            torch.autograd.backward([out, l_aux], [dout, torch.ones_like(l_aux)])
+    else:
+        moe.eval()
+
+        def step():
+            with torch.no_grad():
+                moe(h, mode="vl")
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def other_configs(dev, steps=10, warmup=4):
+    """The other BASELINE.json layer shapes on ONE MI355X, all 32 experts local, eager issue, a few steps each
+    (the headline entry above is configs[1]'s layer; configs[0] is the CPU case = cpu_baseline)."""
+    M, I, E = 1024, 4096, 32
+    out = []
+    moe = build_layer(M, I, E, 1, 0, 197, torch.bfloat16, dev)
+    cases = [("cfg3", "EVE-Large MoE layer, 224 px, B=32/GPU x 237 tokens (the per-rank shape of configs[2]), fwd+bwd", 32, 197, True),
+             ("cfg4", "EVE-Large MoE layer, 480 px VQA shape, B=16/GPU x (901 + 40) tokens (configs[3]), fwd+bwd", 16, 901, True),
+             ("cfg5", "EVE-Large MoE layer, 384 px rerank inference, B=128 x (577 + 40) tokens = 78 976 tokens per forward "
+                      "(configs[4]), eval, forward only, no grad", 128, 577, False)]
+    for name, what, B, n_vis, train in cases:
+        T = n_vis + 40
+        moe.moe.num_vision_tokens = n_vis
+        h, dout = synth_batch(B, T, M, torch.bfloat16, dev, seed=1)
+        ms = time_layer(moe, h, dout, steps, warmup, train)
+        kept = int((moe.moe.last_slot >= 0).sum())
+        flops = (12 if train else 4) * M * I * kept
+        out.append({"name": name, "workload": what, "tokens": B * T, "ms_per_step": round(ms, 4),
+                    "tokens_per_s": round(B * T / ms * 1e3, 1), "kept_assignments": kept,
+                    "expert_gemm_tflops_over_whole_step": round(flops / ms / 1e9, 1), "launch": "eager", "steps": steps})
+        del h, dout
+    del moe
+    torch.cuda.empty_cache()
+    return out
+
+
+def encoder12(dev, steps=5, warmup=2):
+    """BASELINE.json configs[1] as a whole: EVE-Base 12-layer encoder (MoE in layers 10-11, hard modality split in the
+    others, stock fused attention), batch 64 x 237 tokens, bf16, fwd+bwd incl. the gate loss."""
+    import eve_amd
+    torch.manual_seed(0)
+    enc = eve_amd.eve_base_encoder().to(torch.bfloat16).to(dev).train()
+    for layer in enc.layers:
+        moe = getattr(layer, "mlp_moe", None)
+        if moe is not None:
+            moe.moe.blocking_exp_counts = False
+    B, T, M = 64, 237, 768
+    x0, dout = synth_batch(B, T, M, torch.bfloat16, dev, seed=1)
+    mask = torch.ones(B, T, dtype=torch.long, device=dev)
+    params = list(enc.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        x = x0.detach().requires_grad_(True)
+        out = enc(x, mask, mode="vl")
+        gl = enc.gate_loss(0.001)
+        torch.autograd.backward([out, gl], [dout, torch.ones_like(gl)])
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    res = {"workload": "EVE-Base encoder, 12 layers, B=64 x (197 + 40) tokens, bf16, fwd+bwd (BASELINE configs[1]); attention "
+                       "is PyTorch-ROCm's fused SDPA, the FFN branches are this library", "ms_per_step": round(ms, 3),
+           "tokens_per_s": round(B * T / ms * 1e3, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+           "launch": "eager", "steps": steps}
+    del enc, params
+    torch.cuda.empty_cache()
+    return res
+
+
+def gemm_traffic(world, args, B):
+    """HBM bytes per GEMM launch from separate rocprofv3 --pmc passes of THIS workload (tools/collect_profiles.sh:
+    FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE); counters cannot be read from inside the
+    process.  Only trusted when the file was collected with the library that is loaded now (source digest)."""
+    from eve_amd import _lib
+    if not (world == 1 and args.dtype == "bf16" and args.model == "base" and B == 64):
+        return None, None
+    for name in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+        path = os.path.join(REPO, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        rec = json.load(open(path))
+        if rec.get("source_hash") == _lib.source_hash():
+            return rec["avg_hbm_bytes_per_launch"], f"profiles/{name}"
+    return None, "no rocprofv3 --pmc collection matches the loaded library's source digest"
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     # EVE_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo (the all-to-all goes through host memory), to run the
@@ -123,10 +318,7 @@ def main():
     S = B * T
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     moe = build_layer(M, I, E, world, rank, n_vis, dtype, dev)
-
-    g = torch.Generator().manual_seed(1234 + rank)
-    h = torch.nn.functional.layer_norm(torch.randn(B, T, M, generator=g), (M,)).to(dtype).to(dev)
-    dout = torch.randn(B, T, M, generator=g).to(dtype).to(dev)
+    h, dout = synth_batch(B, T, M, dtype, dev, seed=1234 + rank)
     params = [p for p in moe.parameters()]
 
     def eager_step():
@@ -136,7 +328,7 @@ def main():
         out, l_aux, _ = moe(x, mode="vl")
         torch.autograd.backward([out, l_aux], [dout, torch.ones_like(l_aux)])
 
-    # One step is ~50 launches; issued from Python the host is slower than the GPU, so on one GPU the
+    # One step is ~25 launches; issued from Python the host is slower than the GPU, so on one GPU the
     # step (noise draw, forward, full backward) is captured once into a HIP graph and replayed.  With
     # expert parallelism the step contains RCCL all-to-alls and is issued eagerly.
     use_graph = world == 1 and not args.no_graph
@@ -179,10 +371,13 @@ def main():
 
     # kept assignments of the last step (exact K for the algorithmic flop count)
     kept = int((moe.moe.last_slot >= 0).sum().item())
+    C = ops.capacity(S, E, 1.0, 4)
     ffn_ms = prof.get("eve_ffn_fwd", (0.0, 0))[0] + prof.get("eve_ffn_bwd", (0.0, 0))[0]
     # Per step: 6 grouped GEMMs of 2*M*I*K flops each; an eve_ffn_fwd call is 2 launches, an eve_ffn_bwd call 3 (the
-    # two weight-gradient GEMMs share one): 5 launches per step on one GPU, 5 per expert chunk with expert parallelism
-    # (there K counts rank 0's own kept assignments; the rows its experts receive from all ranks are about as many).
+    # two weight-gradient GEMMs share one): 5 launches per step on one GPU, 5 per expert chunk with expert parallelism.
+    # Algorithmic flops count KEPT rows only.  With expert parallelism the owner does not know its peers' fill
+    # counts and processes every capacity row it received (E*C per rank): `achieved` stays algorithmic (rank 0's own
+    # kept count stands in for the rows its experts received: about as many) and `processed_tflops` counts E*C rows.
     launches = 2 * prof.get("eve_ffn_fwd", (0.0, 0))[1] + 3 * prof.get("eve_ffn_bwd", (0.0, 0))[1]
     flops_per_launch = 6.0 * 2.0 * M * I * kept * args.steps / max(launches, 1)
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
@@ -190,20 +385,19 @@ def main():
     if ffn_ms > 0:
         avg_ms = ffn_ms / launches
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "r01_gemm_traffic.json")
-        if world == 1 and args.dtype == "bf16" and args.model == "base" and B == 64 and os.path.exists(tpath):
-            # HBM bytes per launch from separate rocprofv3 --pmc passes of this workload (FETCH_SIZE doubled as the
-            # gfx950 guide prescribes, WRITE_SIZE); counters cannot be read live from inside the process
-            traffic = json.load(open(tpath))["avg_hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_gemm_traffic.json"
+        traffic, traffic_src = gemm_traffic(world, args, B)
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": f"grouped expert-FFN GEMM (eve::grouped_gemm_pp, {launches // max(args.steps, 1)} launches/step computing 6 GEMMs)",
+                    "kernel": f"grouped expert-FFN GEMM (eve::grouped_gemm_pp*, {launches // max(args.steps, 1)} launches/step computing 6 GEMMs)",
                     "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": flops_per_launch,
                     "timing": "HIP events on the launch stream around eve_ffn_fwd / eve_ffn_bwd over the K steps"}
+        if world > 1:
+            roofline["processed_tflops"] = round(achieved * (E * C) / max(kept, 1), 2)
+            roofline["note"] = ("expert parallel: every capacity row received is processed (E*C rows per rank, empty ones "
+                                "included); `achieved` counts kept rows only, `processed_tflops` all processed rows")
 
     if rank == 0:
+        from eve_amd import _lib
         line = {
             "metric": "MoE-layer fwd+bwd tokens/sec", "value": round(S * world * args.steps / elapsed, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -213,16 +407,26 @@ def main():
                                    f"B={B}/GPU x ({n_vis} vision + {args.text_tokens} text) tokens, M={M}, I={I}, E={E} top-2, "
                                    f"capacity_factor 1.0, mode vl", "tokens_per_gpu": S, "kept_assignments": kept,
                        "parallelism": f"ep{world}" if world > 1 else "single",
-                       "launch": "hipgraph replay of the whole step" if use_graph else "eager, one launch per kernel"},
+                       "launch": "hipgraph replay of the whole step" if use_graph else "eager, one launch per kernel",
+                       "library_source_hash": _lib.source_hash()},
             "roofline": roofline,
             "phases_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }
         if rehearsal:
             line["rehearsal"] = "all ranks on cuda:0 over gloo with a host-staged exchange: NOT a measurement"
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args, M, I, E, n_vis, T)
+        if world == 1:
+            del moe, params, h, dout
+            if use_graph:
+                del graphed, step
+            torch.cuda.empty_cache()
+            if not args.no_other_configs:
+                line["other_configs"] = other_configs(dev)
+                line["encoder12"] = encoder12(dev)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args, M, I, E, n_vis, T)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("EVE_MOE_LIB", LIB_PATH)  # A/B experiments: an altern
 F32, BF16 = 0, 1
 MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3
 ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
+FFN_SHARED_GPU = 1
 
 _P, _I, _Z = c_void_p, c_int, c_size_t
 
@@ -25,6 +26,7 @@ _P, _I, _Z = c_void_p, c_int, c_size_t
 SIGNATURES = {
     "eve_moe_abi_version": (c_int, []),
     "eve_moe_last_error": (c_char_p, []),
+    "eve_moe_source_hash": (c_char_p, []),
     "eve_capacity": (c_int, [_I, _I, c_double, _I]),
     "eve_gate_logits_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eve_gate_workspace_bytes": (c_size_t, [_I, _I]),
@@ -45,10 +47,9 @@ SIGNATURES = {
     "eve_split_ln_workspace_bytes": (c_size_t, [_I, _I]),
     "eve_split_ln_bwd": (c_int, [_P] * 8 + [_I] * 6 + [_P, _Z, _P]),
     "eve_split_permute": (c_int, [_P, _P] + [_I] * 7 + [_P]),
-    "eve_ffn_fwd": (c_int, [_P] * 9 + [_I] * 7 + [_P]),
-    "eve_ffn_bwd": (c_int, [_P] * 13 + [_I] * 7 + [_P, _Z, _P]),
+    "eve_ffn_fwd": (c_int, [_P] * 9 + [_I] * 8 + [_P]),
+    "eve_ffn_bwd": (c_int, [_P] * 13 + [_I] * 8 + [_P, _Z, _P]),
     "eve_ffn_bwd_workspace_bytes": (c_size_t, [_I] * 6),
-    "eve_ffn_set_shared_gpu": (_I, [_I]),
 }
 
 _lib = None
@@ -71,8 +72,28 @@ def load():
     got = lib.eve_moe_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"eve_amd: libeve_moe.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    _check_source_hash(lib)
     _lib = lib
     return lib
+
+
+def source_hash() -> str:
+    """Digest of the sources the loaded library was built from (eve_moe_source_hash)."""
+    return load().eve_moe_source_hash().decode()
+
+
+def _check_source_hash(lib) -> None:
+    """The library must have been built from THIS checkout's kernel sources: a stale .so would be tested (and
+    benchmarked) in place of the committed code.  EVE_MOE_LIB builds (A/B experiments) are exempt."""
+    if "EVE_MOE_LIB" in os.environ:
+        return
+    from . import build as _build
+    want = _build.source_hash()
+    got = lib.eve_moe_source_hash().decode()
+    if got != want:
+        raise RuntimeError(
+            f"eve_amd: {LIB_PATH} was built from other sources (library {got}, checkout {want}); rebuild it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'`")
 
 
 def call(name, *args):

@@ -1,48 +1,84 @@
-"""Build libeve_moe.so in-tree: hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+"""Build libeve_moe.so in-tree: hipcc --offload-arch=gfx950 (cross-compiles without a GPU).
+
+    python eve_amd/build.py [--force]          eve_amd/libeve_moe.so
+    python eve_amd/build.py --debug-knobs      eve_amd/libeve_moe_dbg.so: the same library with the EVE_FFN_* A/B
+                                               environment knobs of ffn_mfma.hip compiled in (select it with
+                                               EVE_MOE_LIB=eve_amd/libeve_moe_dbg.so; the shipped library reads no
+                                               environment variable)
+
+The library carries a digest of its sources (eve_moe_source_hash); `eve_amd/_lib.py` compares it with the
+digest of the checkout, so a library built from other sources is refused instead of silently tested.
+"""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+HEADER = os.path.join(HERE, "..", "include", "eve_moe.h")
 OUT = os.path.join(HERE, "libeve_moe.so")
-SOURCES = ["capi.hip", "gate.hip", "permute.hip", "ffn.hip", "ffn_mfma.hip", "multiway.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+OUT_DBG = os.path.join(HERE, "libeve_moe_dbg.so")
+SOURCES = ["capi.hip", "gate.hip", "permute.hip", "ffn.hip", "ffn_mfma.hip", "multiway.hip", "fused.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-const-variable"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(OUT):
+def source_files():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [HEADER]
+
+
+def source_hash() -> str:
+    """sha256 over (file name, contents) of every kernel source and the public header, 16 hex digits."""
+    h = hashlib.sha256()
+    for path in source_files():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def _stale(out: str) -> bool:
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "eve_moe.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in source_files())
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return OUT
+def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False) -> str:
+    out = OUT_DBG if debug_knobs else OUT
+    if not force and not _stale(out):
+        return out
+    digest = source_hash()
     objs = []
-    bdir = os.path.join(HERE, "..", "build", "obj")
+    bdir = os.path.join(HERE, "..", "build", "obj_dbg" if debug_knobs else "obj")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
+        if not os.path.exists(os.path.join(CSRC, src)):
+            continue
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = ["hipcc", *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if src == "capi.hip":
+            cmd.insert(-4, f'-DEVE_SOURCE_HASH="{digest}"')
+        if debug_knobs:
+            cmd.insert(-4, "-DEVE_FFN_DEBUG_KNOBS=1")
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, debug_knobs="--debug-knobs" in sys.argv)

@@ -22,6 +22,11 @@ extern "C" int eve_moe_abi_version(void) { return EVE_MOE_ABI_VERSION; }
 
 extern "C" const char* eve_moe_last_error(void) { return eve::g_err; }
 
+#ifndef EVE_SOURCE_HASH
+#define EVE_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* eve_moe_source_hash(void) { return EVE_SOURCE_HASH; }
+
 // models/sharded_moe.py:150-160 as called at :177: the python float S/E is multiplied by a
 // 0-dim fp32 tensor holding 2*capacity_factor, so product and ceil are fp32 arithmetic.
 extern "C" int eve_capacity(int S, int E, double capacity_factor, int min_capacity) {

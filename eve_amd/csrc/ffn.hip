@@ -234,19 +234,18 @@ using namespace eve;
 
 extern "C" int eve_ffn_fwd(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* z,
                            void* a, void* y, const int32_t* rows, int G, int E_local, int R, int M, int I, int act,
-                           int dtype, void* stream) {
+                           int dtype, int flags, void* stream) {
   EVE_REQUIRE(x && w1 && b1 && w2 && b2 && a && y, EVE_ERR_ARG, "eve_ffn_fwd: null pointer");
   if (int rc = check_ffn("eve_ffn_fwd", G, E_local, R, M, I, act, dtype)) return rc;
+  EVE_REQUIRE((flags & ~EVE_FFN_SHARED_GPU) == 0, EVE_ERR_ARG, "eve_ffn_fwd: unknown flags 0x%x", flags);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == EVE_BF16) {
     if (ffn_mfma_supported(M, I))
-      return ffn_fwd_mfma(x, w1, b1, w2, b2, z, a, y, rows, G, E_local, R, M, I, act, st);
+      return ffn_fwd_mfma(x, w1, b1, w2, b2, z, a, y, rows, G, E_local, R, M, I, act, (flags & EVE_FFN_SHARED_GPU) != 0, st);
     return ffn_fwd_generic<bf16_t>(x, w1, b1, w2, b2, z, a, y, rows, G, E_local, R, M, I, act, st);
   }
   return ffn_fwd_generic<float>(x, w1, b1, w2, b2, z, a, y, rows, G, E_local, R, M, I, act, st);
 }
-
-extern "C" int eve_ffn_set_shared_gpu(int shared) { return ffn_set_shared_gpu(shared); }
 
 extern "C" size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype) {
   (void)R;
@@ -256,15 +255,16 @@ extern "C" size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, 
 
 extern "C" int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2,
                            void* dz, void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G,
-                           int E_local, int R, int M, int I, int act, int dtype, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+                           int E_local, int R, int M, int I, int act, int dtype, int flags, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   EVE_REQUIRE(dy && x && z && a && w1 && w2 && dz && dx && dw1 && db1 && dw2 && db2, EVE_ERR_ARG, "eve_ffn_bwd: null pointer");
   if (int rc = check_ffn("eve_ffn_bwd", G, E_local, R, M, I, act, dtype)) return rc;
+  EVE_REQUIRE((flags & ~EVE_FFN_SHARED_GPU) == 0, EVE_ERR_ARG, "eve_ffn_bwd: unknown flags 0x%x", flags);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == EVE_BF16) {
     if (ffn_mfma_supported(M, I))
-      return ffn_bwd_mfma(dy, x, z, a, w1, w2, dz, dx, dw1, db1, dw2, db2, rows, G, E_local, R, M, I, act, workspace,
-                          workspace_bytes, st);
+      return ffn_bwd_mfma(dy, x, z, a, w1, w2, dz, dx, dw1, db1, dw2, db2, rows, G, E_local, R, M, I, act,
+                          (flags & EVE_FFN_SHARED_GPU) != 0, workspace, workspace_bytes, st);
     return ffn_bwd_generic<bf16_t>(dy, x, z, a, w1, w2, dz, dx, dw1, db1, dw2, db2, rows, G, E_local, R, M, I, act, st);
   }
   return ffn_bwd_generic<float>(dy, x, z, a, w1, w2, dz, dx, dw1, db1, dw2, db2, rows, G, E_local, R, M, I, act, st);

@@ -1334,6 +1334,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 bool ffn_mfma_supported(int M, int I) { return M % 256 == 0 && I % 256 == 0; }
 
+// Kernel attributes (the dynamic-LDS limit) and the CU count belong to a DEVICE: a process that launches on a
+// second GPU must raise the limit there as well.  One bit per device and kernel, set after the attribute call
+// succeeded with that device current; racing threads at worst repeat the (idempotent) call.
+constexpr int kMaxDevices = 64;
+static int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool done(int dev) const { return (mask.load(std::memory_order_acquire) >> dev) & 1ull; }
+  void set(int dev) { mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
+static int reserve_lds(PerDeviceOnce& once, const void* kern, int bytes) {
+  const int dev = current_device();
+  if (once.done(dev)) return EVE_OK;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    set_error("ffn_mfma: cannot reserve %d bytes of LDS on device %d", bytes, dev);
+    return EVE_ERR_LAUNCH;
+  }
+  once.set(dev);
+  return EVE_OK;
+}
+
 template <int BM, int NS, bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
 static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
   using C_ = Cfg<BM, NS>;
@@ -1342,15 +1367,8 @@ static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
 #define EVE_MFMA_LAUNCH(A)                                                                                   \
   do {                                                                                                       \
     auto kern = grouped_gemm_mfma<BM, NS, A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD>;                           \
-    static bool attr_done = false;                                                                           \
-    if (!attr_done) {                                                                                        \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              C_::kLds) != hipSuccess) {                                                     \
-        set_error("ffn_mfma: cannot reserve %d bytes of LDS", C_::kLds);                                     \
-        return EVE_ERR_LAUNCH;                                                                               \
-      }                                                                                                      \
-      attr_done = true;                                                                                      \
-    }                                                                                                        \
+    static PerDeviceOnce once;                                                                               \
+    if (int rc_ = reserve_lds(once, reinterpret_cast<const void*>(kern), C_::kLds)) return rc_;              \
     hipLaunchKernelGGL(kern, grid, dim3(C_::kThreads), C_::kLds, st, d);                                     \
   } while (0)
   if constexpr (EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT) {
@@ -1371,17 +1389,20 @@ static int launch_cfg(const MfmaDesc& d, int act, hipStream_t st) {
   return EVE_OK;
 }
 
-static int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
+static int cu_count() {  // of the current device; cached per device
+  static std::atomic<int> n[kMaxDevices];
+  const int dev = current_device();
+  int v = n[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (!(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)) v = 256;
+    n[dev].store(v, std::memory_order_relaxed);
   }
-  return n;
+  return v;
 }
 
-// Debug knobs for A/B timing, read from the environment once per process:
+// Debug knobs for A/B timing.  They exist only in a build with -DEVE_FFN_DEBUG_KNOBS (`python eve_amd/build.py
+// --debug-knobs` writes eve_amd/libeve_moe_dbg.so; select it with EVE_MOE_LIB); the shipped library reads no
+// environment variable.  Read once per process:
 //   EVE_FFN_KERNEL=lockstep    the older lock-step 256-row kernel instead of the ping-pong kernels
 //   EVE_FFN_PERSIST=0          one tile per workgroup instead of the persistent kernel
 //   EVE_FFN_PERSIST_ACT=0      ... for the activation-epilogue launches only
@@ -1393,6 +1414,7 @@ struct Knobs {
   int tile_rows, ksplit;
 };
 static const Knobs& knobs() {
+#ifdef EVE_FFN_DEBUG_KNOBS
   static const Knobs k = [] {
     auto env = [](const char* n) { return getenv(n); };
     Knobs q;
@@ -1404,15 +1426,17 @@ static const Knobs& knobs() {
     q.ksplit = env("EVE_FFN_KSPLIT") ? atoi(env("EVE_FFN_KSPLIT")) : 0;
     return q;
   }();
+#else
+  static const Knobs k = {true, true, true, false, 0, 0};
+#endif
   return k;
 }
-static std::atomic<int> g_shared_gpu{0};  // eve_ffn_set_shared_gpu
-int ffn_set_shared_gpu(int shared) { return g_shared_gpu.exchange(shared ? 1 : 0); }
 static bool use_pingpong() { return knobs().pingpong; }
-static bool use_persistent() { return knobs().persist && !g_shared_gpu.load(std::memory_order_relaxed); }
+// `shared` (EVE_FFN_SHARED_GPU of the call's flags): other kernels run beside this launch, so no persistent grid
+static bool use_persistent(bool shared) { return knobs().persist && !shared; }
 
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI, int WR = 4>
-static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc* d2 = nullptr) {
+static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, const MfmaDesc* d2 = nullptr) {
   constexpr int kEpi = 8 * 32 * EPI_LD * 4;
   constexpr int kLds = 5 * 256 * BKI * 2 > kEpi ? 5 * 256 * BKI * 2 : kEpi;
   auto blocks = [](const MfmaDesc& q) {
@@ -1428,7 +1452,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
   // epilogues run it with resynchronised E phases (kResync; EVE_FFN_PERSIST_ACT=0 selects the one-tile kernel
   // for A/B timing: the persistent one measured 2 % faster on those launches).
   const bool act_epi = EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT;
-  const bool persist = use_persistent() && (!act_epi || knobs().persist_act) &&
+  const bool persist = use_persistent(shared) && (!act_epi || knobs().persist_act) &&
                        EPI != MEPI_STORE_F32 && (!WGRAD || d.G == d.E_local) && pr.ntotal > cu_count();
   constexpr int kStage = 8 * 16 * EPI_LD * 4;
   constexpr int kLdsP = (5 * 256 * BKI * 2 + kStage > 160 * 1024) ? 5 * 256 * BKI * 2 : 5 * 256 * BKI * 2 + kStage;
@@ -1436,24 +1460,12 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
 #define EVE_PP_LAUNCH(A)                                                                                     \
   do {                                                                                                       \
     auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                                \
-    static bool attr_done = false;                                                                           \
-    if (!attr_done) {                                                                                        \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              kLds) != hipSuccess) {                                                         \
-        set_error("ffn_mfma: cannot reserve %d bytes of LDS", kLds);                                         \
-        return EVE_ERR_LAUNCH;                                                                               \
-      }                                                                                                      \
-      attr_done = true;                                                                                      \
-    }                                                                                                        \
+    static PerDeviceOnce once, oncep;                                                                        \
     auto kernp = grouped_gemm_ppp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                           \
-    static bool attrp_done = false;                                                                          \
-    if (persist && !attrp_done) {                                                                            \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernp), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              kLdsP) != hipSuccess) {                                                        \
-        set_error("ffn_mfma: cannot reserve %d bytes of LDS", kLdsP);                                        \
-        return EVE_ERR_LAUNCH;                                                                               \
-      }                                                                                                      \
-      attrp_done = true;                                                                                     \
+    if (persist) {                                                                                           \
+      if (int rc_ = reserve_lds(oncep, reinterpret_cast<const void*>(kernp), kLdsP)) return rc_;             \
+    } else {                                                                                                 \
+      if (int rc_ = reserve_lds(once, reinterpret_cast<const void*>(kern), kLds)) return rc_;                \
     }                                                                                                        \
     if (persist) hipLaunchKernelGGL(kernp, grid, dim3(512), kLdsP, st, pr);                                  \
     else hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, pr);                                            \
@@ -1482,7 +1494,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, const MfmaDesc*
 // 256 CUs, where 384 tiles of 256 rows leave the second wave half empty); 128 x 256 tiles (4 waves) when
 // the row extent is small enough that a larger tile would be mostly padding.
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
-static int launch(const MfmaDesc& d, int act, hipStream_t st) {
+static int launch(const MfmaDesc& d, int act, hipStream_t st, bool shared) {
   const int force = knobs().tile_rows;  // debug knob: force 128, 192 or 256
   const bool small = !WGRAD && (force == 128 ||
                                 (!force && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024))));
@@ -1493,25 +1505,25 @@ static int launch(const MfmaDesc& d, int act, hipStream_t st) {
     const long cost256 = ceil_div(per * ceil_div(d.Mext, 256), cus) * 256;
     const long cost192 = ceil_div(per * ceil_div(d.Mext, 192), cus) * 192;
     const bool use192 = force ? force == 192 : cost192 * 10 < cost256 * 9;
-    if (use192) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, 64, 3>(d, act, st);
+    if (use192) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, 64, 3>(d, act, st, shared);
   }
-  return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, (A_COL && B_COL) ? 32 : 64>(d, act, st);
+  return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, (A_COL && B_COL) ? 32 : 64>(d, act, st, shared);
 }
 
 int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* z, void* a,
-                 void* y, const int32_t* rows, int G, int E_local, int R, int M, int I, int act, hipStream_t st) {
+                 void* y, const int32_t* rows, int G, int E_local, int R, int M, int I, int act, bool shared, hipStream_t st) {
   MfmaDesc d{};
   d.G = G; d.E_local = E_local; d.rows = rows; d.Mext = R;
   // z = x @ w1^T + b1 ; a = act(z)
   d.A = (const bf16_t*)x; d.a_g = (long)R * M; d.lda = M;
   d.B = (const bf16_t*)w1; d.b_g = (long)I * M; d.ldb = M;
   d.C = (bf16_t*)z; d.C2 = (bf16_t*)a; d.c_g = (long)R * I; d.ldc = I; d.bias = (const bf16_t*)b1; d.N = I; d.K = M;
-  if (int rc = launch<false, false, MEPI_BIAS_ACT, false, false>(d, act, st)) return rc;
+  if (int rc = launch<false, false, MEPI_BIAS_ACT, false, false>(d, act, st, shared)) return rc;
   // y = a @ w2^T + b2
   d.A = (const bf16_t*)a; d.a_g = (long)R * I; d.lda = I;
   d.B = (const bf16_t*)w2; d.b_g = (long)M * I; d.ldb = I;
   d.C = (bf16_t*)y; d.C2 = nullptr; d.c_g = (long)R * M; d.ldc = M; d.bias = (const bf16_t*)b2; d.N = M; d.K = I;
-  return launch<false, false, MEPI_BIAS, false, false>(d, act, st);
+  return launch<false, false, MEPI_BIAS, false, false>(d, act, st, shared);
 }
 
 // both weight-gradient GEMMs of a backward pass in one launch of grouped_gemm_pp_wgrad
@@ -1527,14 +1539,8 @@ static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st
   pr.n0 = blocks(d);
   pr.ntotal = pr.n0 + blocks(d2);
   auto kern = grouped_gemm_pp_wgrad<EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) {
-      set_error("ffn_mfma: cannot reserve %d bytes of LDS", kLds);
-      return EVE_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static PerDeviceOnce once;
+  if (int rc = reserve_lds(once, reinterpret_cast<const void*>(kern), kLds)) return rc;
   hipLaunchKernelGGL(kern, dim3(pr.ntotal), dim3(512), kLds, st, pr);
   EVE_CHECK_LAUNCH("grouped_gemm_pp_wgrad");
   return EVE_OK;
@@ -1566,7 +1572,7 @@ size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int M, int I) {
 
 int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2, void* dz,
                  void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G, int E_local, int R,
-                 int M, int I, int act, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                 int M, int I, int act, bool shared, void* workspace, size_t workspace_bytes, hipStream_t st) {
   MfmaDesc d{};
   d.G = G; d.E_local = E_local; d.rows = rows;
   // dz = (dy @ w2) * act'(z): A = dy [R,M] row-major, B = w2 [M,I] k-major
@@ -1574,12 +1580,12 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   d.A = (const bf16_t*)dy; d.a_g = (long)R * M; d.lda = M;
   d.B = (const bf16_t*)w2; d.b_g = (long)M * I; d.ldb = I;
   d.C = (bf16_t*)dz; d.c_g = (long)R * I; d.ldc = I; d.Zin = (const bf16_t*)z; d.N = I; d.K = M;
-  if (int rc = launch<false, true, MEPI_DACT, false, false>(d, act, st)) return rc;
+  if (int rc = launch<false, true, MEPI_DACT, false, false>(d, act, st, shared)) return rc;
   // dx = dz @ w1: A = dz [R,I] row-major, B = w1 [I,M] k-major
   d.A = (const bf16_t*)dz; d.a_g = (long)R * I; d.lda = I;
   d.B = (const bf16_t*)w1; d.b_g = (long)I * M; d.ldb = M;
   d.C = (bf16_t*)dx; d.c_g = (long)R * M; d.ldc = M; d.Zin = nullptr; d.N = M; d.K = I;
-  if (int rc = launch<false, true, MEPI_STORE, false, false>(d, act, st)) return rc;
+  if (int rc = launch<false, true, MEPI_STORE, false, false>(d, act, st, shared)) return rc;
   // dw2[e] = sum_g dy[g]^T @ a[g]  ([M,I]);  db2[e] = column sums of dy
   d.Mext = M;
   d.A = (const bf16_t*)dy; d.a_g = (long)R * M; d.lda = M;
@@ -1619,10 +1625,10 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
       return EVE_OK;
     }
     if (!knobs().wgrad32) return launch_pp_wgrad<MEPI_STORE>(d, d1, st);  // one launch for both GEMMs
-    return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, &d1);  // debug knob: all tiles 32 deep (persistent)
+    return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, shared, &d1);  // debug knob: all tiles 32 deep (persistent)
   }
-  if (int rc = launch<true, true, MEPI_STORE, true, true>(d, act, st)) return rc;
-  return launch<true, true, MEPI_STORE, true, true>(d1, act, st);
+  if (int rc = launch<true, true, MEPI_STORE, true, true>(d, act, st, shared)) return rc;
+  return launch<true, true, MEPI_STORE, true, true>(d1, act, st, shared);
 }
 
 }  // namespace eve

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   const int i1 = idx[2 * s], i2 = idx[2 * s + 1];
   const bool k1 = loc[2 * s] < C, k2 = loc[2 * s + 1] < C;
   const float g1 = k1 ? g[i1] : 0.f, g2 = k2 ? g[i2] : 0.f;
-  const float dw1 = d_weight[2 * s], dw2 = d_weight[2 * s + 1];
+  const float dw1 = d_weight ? d_weight[2 * s] : 0.f, dw2 = d_weight ? d_weight[2 * s + 1] : 0.f;
   const float sum = g1 + g2;
   float dg1, dg2;
   if (sum >= kEps) {  // clamp inactive: w_k = g_k / (g1 + g2)
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void gate_bwd32_kernel(const float* __restrict
     const bool k1 = loc[2 * sc] < C, k2 = loc[2 * sc + 1] < C;
     const float gi1 = __shfl(g, tk * 32 + i1, 64), gi2 = __shfl(g, tk * 32 + i2, 64);
     const float g1 = k1 ? gi1 : 0.f, g2 = k2 ? gi2 : 0.f;
-    const float dw1 = d_weight[2 * sc], dw2 = d_weight[2 * sc + 1];
+    const float dw1 = d_weight ? d_weight[2 * sc] : 0.f, dw2 = d_weight ? d_weight[2 * sc + 1] : 0.f;
     const float sum = g1 + g2;
     float dg1, dg2;
     if (sum >= kEps) {  // clamp inactive: w_k = g_k / (g1 + g2)
@@ -1299,7 +1299,7 @@ extern "C" int eve_gate_top2_fwd_noalloc(const float* logits, const float* noise
 extern "C" int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const int32_t* loc, const float* d_weight,
                                  const float* d_l_aux, const int64_t* exp_counts, int S, int E, int C, float* dlogits,
                                  void* stream) {
-  EVE_REQUIRE(gates && idx && loc && d_weight && exp_counts && dlogits, EVE_ERR_ARG, "eve_gate_top2_bwd: null pointer");
+  EVE_REQUIRE(gates && idx && loc && exp_counts && dlogits, EVE_ERR_ARG, "eve_gate_top2_bwd: null pointer");
   EVE_REQUIRE(S > 0 && E > 0 && C > 0, EVE_ERR_ARG, "eve_gate_top2_bwd: bad shape");
   if (E <= 32) {
     const int grid = max(1, min(ceil_div(S, 8), 4096));

@@ -143,12 +143,20 @@ def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int, noise_is_unifor
     return r
 
 
-def gate_top2_bwd(r: Routing, d_weight: torch.Tensor, d_l_aux: Optional[torch.Tensor]) -> torch.Tensor:
+def gate_top2_bwd_raw(gates, idx, loc, exp_counts, S: int, E: int, C: int, d_weight: Optional[torch.Tensor],
+                      d_l_aux: Optional[torch.Tensor]) -> torch.Tensor:
+    """dlogits [S,E] from d_weight [S,2] (None = no gradient reached the combine weights) and d_l_aux [1]."""
+    if d_weight is not None:
+        d_weight = d_weight.contiguous()
     _chk(d_weight, "d_weight", torch.float32), _chk(d_l_aux, "d_l_aux", torch.float32)
-    dlogits = torch.empty(r.S, r.E, dtype=torch.float32, device=r.gates.device)
-    PROFILE.call("eve_gate_top2_bwd", _p(r.gates), _p(r.idx), _p(r.loc), _p(d_weight), _p(d_l_aux), _p(r.exp_counts),
-              r.S, r.E, r.C, _p(dlogits), _stream())
+    dlogits = torch.empty(S, E, dtype=torch.float32, device=gates.device)
+    PROFILE.call("eve_gate_top2_bwd", _p(gates), _p(idx), _p(loc), _p(d_weight), _p(d_l_aux), _p(exp_counts),
+              S, E, C, _p(dlogits), _stream())
     return dlogits
+
+
+def gate_top2_bwd(r: Routing, d_weight: Optional[torch.Tensor], d_l_aux: Optional[torch.Tensor]) -> torch.Tensor:
+    return gate_top2_bwd_raw(r.gates, r.idx, r.loc, r.exp_counts, r.S, r.E, r.C, d_weight, d_l_aux)
 
 
 def gate_wgrad(h2d, vemb, temb, dlogits, T: int, n_vis: int, mode: int) -> torch.Tensor:
@@ -235,8 +243,9 @@ def combine_bwd(dout: torch.Tensor, y: torch.Tensor, slot, slot_token, slot_weig
     return dy, dw
 
 
-def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True):
-    """x [G,R,M]; w1 [E_l,I,M]; b1 [E_l,I]; w2 [E_l,M,I]; b2 [E_l,M] -> (z|None, a, y)."""
+def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True, shared_gpu: bool = False):
+    """x [G,R,M]; w1 [E_l,I,M]; b1 [E_l,I]; w2 [E_l,M,I]; b2 [E_l,M] -> (z|None, a, y).
+    `shared_gpu`: other kernels (RCCL exchanges) run beside these launches (EVE_FFN_SHARED_GPU)."""
     for t, n in ((x, "x"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
         _chk(t, n, x.dtype)
     _chk(rows, "rows", torch.int32)
@@ -247,24 +256,11 @@ def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True):
     a = torch.empty(G, R, I, dtype=x.dtype, device=x.device)
     y = torch.empty(G, R, M, dtype=x.dtype, device=x.device)
     PROFILE.call("eve_ffn_fwd", _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(z), _p(a), _p(y), _p(rows), G, E_l, R, M, I,
-              act, _dt(x), _stream())
+              act, _dt(x), _lib.FFN_SHARED_GPU if shared_gpu else 0, _stream())
     return z, a, y
 
 
-class shared_gpu:
-    """`with ops.shared_gpu():` -- FFN launches issued inside leave room for other kernels (RCCL exchanges) on
-    the GPU: one workgroup per tile instead of persistent workgroups (eve_ffn_set_shared_gpu)."""
-
-    def __enter__(self):
-        self.prev = _lib.load().eve_ffn_set_shared_gpu(1)
-        return self
-
-    def __exit__(self, *exc):
-        _lib.load().eve_ffn_set_shared_gpu(self.prev)
-        return False
-
-
-def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int, grads_out=None):
+def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int, grads_out=None, shared_gpu: bool = False):
     """-> (dx [G,R,M], dw1, db1, dw2, db2) with the shapes / dtype of the forward operands.
     `grads_out` = (dw1, db1, dw2, db2) to write the parameter gradients into caller-provided tensors."""
     for t, n in ((dy, "dy"), (x, "x"), (z, "z"), (a, "a"), (w1, "w1"), (w2, "w2")):
@@ -287,7 +283,7 @@ def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int, grads_out=None):
     nbytes = _lib.load().eve_ffn_bwd_workspace_bytes(G, E_l, R, M, I, _dt(x))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     PROFILE.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),
-              _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _p(ws), nbytes, _stream())
+              _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _lib.FFN_SHARED_GPU if shared_gpu else 0, _p(ws), nbytes, _stream())
     return dx, dw1, db1, dw2, db2
 
 

@@ -149,9 +149,6 @@ class _Done:
         return True
 
 
-_list_exchange_ok = True
-
-
 class _PackedWork:
     """all_to_all_single on packed copies; `wait()` unpacks into the receive views."""
 
@@ -165,25 +162,35 @@ class _PackedWork:
         return True
 
 
+def _exchange_form(group, on_gpu: bool) -> str:
+    """Which collective moves per-peer views, decided from the group's backend ALONE so that every rank of the
+    group takes the same branch (a rank that fell back on its own while its peers did not would pair different
+    collectives and hang the job):
+      'staged'  GPU rows over a gloo group: through host memory (several ranks on ONE GPU, rehearsal only);
+      'list'    RCCL (backend 'nccl'): asynchronous list-form all_to_all straight on the views, no packing copy;
+      'packed'  anything else (gloo on CPU tensors, ...): all_to_all_single on packed copies."""
+    backend = str(dist.get_backend(group)).lower()
+    if on_gpu and backend == "gloo":
+        return "staged"
+    if on_gpu and "nccl" in backend:
+        return "list"
+    return "packed"
+
+
 def _exchange_views(group, send, recv):
     """Peer p gets `send[p]` and `recv[p]` is filled from peer p; every tensor is a contiguous view.  Returns a
     work handle: `wait()` makes the current stream wait for the exchange, which runs on RCCL's own stream -- so
     kernels launched on the current stream in the meantime overlap it."""
-    if send[0].is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one GPU: through host memory
+    form = _exchange_form(group, send[0].is_cuda)
+    if form == "staged":
         host_in = torch.stack([t.cpu() for t in send])
         host_out = torch.empty_like(host_in)
         dist.all_to_all_single(host_out, host_in, group=group)
         for p, t in enumerate(recv):
             t.copy_(host_out[p])
         return _Done()
-    global _list_exchange_ok
-    if _list_exchange_ok:
-        try:
-            return dist.all_to_all(recv, send, group=group, async_op=True)
-        except (RuntimeError, NotImplementedError) as exc:  # a backend without the list form: pack and say so
-            import warnings
-            warnings.warn(f"eve_amd: all_to_all on tensor lists failed ({exc}); exchanging packed copies instead")
-            _list_exchange_ok = False
+    if form == "list":
+        return dist.all_to_all(recv, send, group=group, async_op=True)
     packed_in = torch.stack(send)
     packed_out = torch.empty_like(packed_in)
     return _PackedWork(dist.all_to_all_single(packed_out, packed_in, group=group, async_op=True), packed_in, packed_out, recv)
@@ -233,9 +240,9 @@ class _EPPipelineFn(torch.autograd.Function):
             lo = c * step
             works[c].wait()
             x = recv[c].view(ep * step, C, M)
-            with ops.shared_gpu():  # RCCL's kernels hold CUs beside these launches
-                z, a, y = ops.ffn_fwd(x, w1[lo:lo + step], b1[lo:lo + step], w2[lo:lo + step], b2[lo:lo + step], None,
-                                      act, save_z=need_grad)
+            # RCCL's kernels hold CUs beside these launches: one workgroup per tile (EVE_FFN_SHARED_GPU)
+            z, a, y = ops.ffn_fwd(x, w1[lo:lo + step], b1[lo:lo + step], w2[lo:lo + step], b2[lo:lo + step], None,
+                                  act, save_z=need_grad, shared_gpu=True)
             y4 = y.view(ep, step, C, M)
             back.append(_exchange_views(group, [y4[p] for p in range(ep)], [out4[p, lo:lo + step] for p in range(ep)]))
             keep.append(y)
@@ -272,10 +279,9 @@ class _EPPipelineFn(torch.autograd.Function):
             lo = c * step
             x, z, a = saved[3 * c:3 * c + 3]
             works[c].wait()
-            with ops.shared_gpu():
-                dx, *_ = ops.ffn_bwd(recv[c].view(ep * step, C, M), x, z, a, w1[lo:lo + step], w2[lo:lo + step], None,
-                                     act, grads_out=(dw1[lo:lo + step], db1[lo:lo + step], dw2[lo:lo + step],
-                                                     db2[lo:lo + step]))
+            dx, *_ = ops.ffn_bwd(recv[c].view(ep * step, C, M), x, z, a, w1[lo:lo + step], w2[lo:lo + step], None,
+                                 act, grads_out=(dw1[lo:lo + step], db1[lo:lo + step], dw2[lo:lo + step],
+                                                 db2[lo:lo + step]), shared_gpu=True)
             dx4 = dx.view(ep, step, C, M)
             back.append(_exchange_views(group, [dx4[p] for p in range(ep)], [dxd4[p, lo:lo + step] for p in range(ep)]))
             keep.append(dx)
@@ -290,7 +296,11 @@ class _GateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, noise: Tensor, C: int, noise_is_uniform: bool = False):  # type: ignore[override]
         r = ops.gate_top2(logits.contiguous(), noise.contiguous(), C, noise_is_uniform)
-        ctx.routing = r
+        # only what the backward reads, and through save_for_backward: keeping the Routing object (which holds
+        # r.weight, an OUTPUT of this Function) on ctx would tie output -> grad_fn -> ctx -> output into a cycle
+        # that only Python's cyclic GC frees
+        ctx.save_for_backward(r.gates, r.idx, r.loc, r.exp_counts)
+        ctx.sec = (r.S, r.E, r.C)
         ctx.set_materialize_grads(False)  # no zero tensors for the index outputs' "gradients"
         outs = (r.weight, r.l_aux.view(()), r.slot, r.slot_token, r.slot_weight, r.rows, r.exp_counts, r.idx, r.loc)
         ctx.mark_non_differentiable(*outs[2:])
@@ -298,11 +308,10 @@ class _GateFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_weight, d_l_aux, *unused):  # type: ignore[override]
-        r = ctx.routing
-        if d_weight is None:
-            d_weight = torch.zeros_like(r.weight)
+        gates, idx, loc, exp_counts = ctx.saved_tensors
+        S, E, C = ctx.sec
         dl = None if d_l_aux is None else d_l_aux.reshape(1).float().contiguous()
-        return ops.gate_top2_bwd(r, d_weight.contiguous(), dl), None, None, None
+        return ops.gate_top2_bwd_raw(gates, idx, loc, exp_counts, S, E, C, d_weight, dl), None, None, None
 
 
 class _RouteDispatchFn(torch.autograd.Function):
@@ -326,9 +335,10 @@ class _RouteDispatchFn(torch.autograd.Function):
         C = ops.capacity(S, E, cap_factor, min_capacity)
         r = ops.gate_top2(logits, noise.contiguous(), C, noise_is_uniform)
         xd = ops.dispatch_fwd(h2d, ve, te, r.slot_token, T, n_vis, mode)
-        ctx.routing, ctx.dims = r, (B, T, M, n_vis, mode)
+        ctx.dims, ctx.sec = (B, T, M, n_vis, mode), (r.S, r.E, r.C)
         ctx.set_materialize_grads(False)  # no zero tensors for the index outputs' "gradients"
-        ctx.save_for_backward(h2d, wg32, ve, te)
+        # (not the Routing object: it holds r.weight, an output of this Function -- a reference cycle through ctx)
+        ctx.save_for_backward(h2d, wg32, ve, te, r.gates, r.idx, r.loc, r.exp_counts, r.slot)
         ctx.param_dtypes = (wg.dtype, None if vemb is None else vemb.dtype, None if temb is None else temb.dtype)
         outs = (xd, r.weight, r.l_aux.view(()), r.slot, r.slot_token, r.slot_weight, r.rows, r.exp_counts)
         ctx.mark_non_differentiable(*outs[3:])
@@ -336,23 +346,20 @@ class _RouteDispatchFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxd, d_weight, d_l_aux, *unused):  # type: ignore[override]
-        r = ctx.routing
         B, T, M, n_vis, mode = ctx.dims
-        h2d, wg32, ve, te = ctx.saved_tensors
-        S = B * T
-        if d_weight is None:
-            d_weight = torch.zeros_like(r.weight)
+        h2d, wg32, ve, te, gates, idx, loc, exp_counts, slot = ctx.saved_tensors
+        S, E, C = ctx.sec
         dl = None if d_l_aux is None else d_l_aux.reshape(1).float().contiguous()
-        dlogits = ops.gate_top2_bwd(r, d_weight.contiguous(), dl)
+        dlogits = ops.gate_top2_bwd_raw(gates, idx, loc, exp_counts, S, E, C, d_weight, dl)
         if dxd is None:
-            dxd = torch.zeros(r.E * r.C, M, dtype=h2d.dtype, device=h2d.device)
+            dxd = torch.zeros(E * C, M, dtype=h2d.dtype, device=h2d.device)
         wg_dt, v_dt, t_dt = ctx.param_dtypes
         want_v = mode in (_lib.MODE_VL, _lib.MODE_VISION) and ctx.needs_input_grad[2]
         want_t = mode in (_lib.MODE_VL, _lib.MODE_TEXT) and ctx.needs_input_grad[3]
         e_dt = v_dt if v_dt is not None else t_dt
         fused_dt = e_dt if e_dt in (torch.float32, torch.bfloat16) and v_dt in (None, e_dt) and t_dt in (None, e_dt) \
             else torch.float32
-        dh, dv, dt = ops.route_bwd(dxd.contiguous(), r.slot, dlogits, wg32, S, T, n_vis, mode, want_v, want_t, fused_dt)
+        dh, dv, dt = ops.route_bwd(dxd.contiguous(), slot, dlogits, wg32, S, T, n_vis, mode, want_v, want_t, fused_dt)
         dwg = ops.gate_wgrad(h2d, ve, te, dlogits, T, n_vis, mode).to(wg_dt) if ctx.needs_input_grad[1] else None
         if dv is not None and dv.dtype != v_dt:
             dv = dv.to(v_dt)
@@ -393,10 +400,14 @@ def top2gating(logits: Tensor, capacity_factor: float, min_capacity: int,
         noise, is_uniform = _draw_noise(logits.shape, logits.device)
     C = ops.capacity(S, E, capacity_factor, min_capacity)
     weight, l_aux, slot, _, _, _, exp_counts, _, _ = _GateFn.apply(logits, noise, C, is_uniform)
+    # a token's two slots are distinct (different experts), dropped choices (slot -1) go to a dummy last column:
+    # no index appears twice in a row, so the scatter is deterministic and slot 0 can never be overwritten by a
+    # dropped choice's zero
     keep = slot >= 0
-    combine = torch.zeros(S, E * C, dtype=torch.float32, device=logits.device)
-    combine = combine.scatter(1, slot.clamp(min=0).long(), weight * keep)
-    combine = combine.view(S, E, C)
+    col = torch.where(keep, slot, torch.full_like(slot, E * C)).long()
+    combine = torch.zeros(S, E * C + 1, dtype=torch.float32, device=logits.device)
+    combine = combine.scatter(1, col, weight * keep)[:, :E * C]
+    combine = combine.reshape(S, E, C)
     return l_aux, combine, combine.bool(), exp_counts.to("cpu")
 
 
@@ -496,10 +507,12 @@ class MOELayer(nn.Module):
         self.time_salltoall = 0.0
         self.time_moe = 0.0
         self.wall_clock_breakdown = False
-        # exp_counts is handed back as a CPU int64 tensor like the reference's (:199).  By
-        # default the device->host copy is asynchronous (pinned buffer): the values are valid
-        # once the stream has been synchronised.  Set True for the reference's blocking copy.
-        self.blocking_exp_counts = False
+        # exp_counts is handed back as a CPU int64 tensor like the reference's (:199), by default with the
+        # reference's blocking `.to('cpu')`: valid the moment forward returns.  Opt-in False: the copy goes
+        # asynchronously into a pinned buffer (no host sync per layer) and is valid once the stream has been
+        # synchronised.  Under HIP-graph capture the copy node targets a pinned buffer owned by THIS layer.
+        self.blocking_exp_counts = True
+        self._graph_counts_host: Optional[Tensor] = None
         self.l_aux = None
         self.exp_counts = None
         self.noise_override: Optional[Tensor] = None  # tests: replaces the Gumbel draw once
@@ -511,6 +524,22 @@ class MOELayer(nn.Module):
             self.text_embed = nn.Parameter(torch.zeros(self.gate.model_dim))
             trunc_normal_(self.text_embed, std=0.02)
             self.num_vision_tokens = num_tokens
+
+    def _host_counts(self, exp_counts: Tensor) -> Tensor:
+        if torch.cuda.is_current_stream_capturing():
+            # under HIP-graph capture nothing may be allocated or synchronised: the copy node targets this layer's
+            # own pinned buffer, refilled by every replay (two layers captured in one graph keep separate counts)
+            if self._graph_counts_host is None:
+                raise RuntimeError("eve_amd: run the layer once eagerly before capturing it into a graph")
+            self._graph_counts_host.copy_(exp_counts, non_blocking=True)
+            return self._graph_counts_host
+        if self._graph_counts_host is None or self._graph_counts_host.shape != exp_counts.shape:
+            self._graph_counts_host = torch.empty(exp_counts.shape, dtype=exp_counts.dtype, pin_memory=True)
+        if self.blocking_exp_counts:
+            return exp_counts.to("cpu")
+        host = torch.empty(exp_counts.shape, dtype=exp_counts.dtype, pin_memory=True)
+        host.copy_(exp_counts, non_blocking=True)
+        return host
 
     def _set_ep_group(self, ep_group) -> None:
         self.ep_group = ep_group
@@ -566,7 +595,7 @@ class MOELayer(nn.Module):
             h, gate.wg.weight, vemb_in, temb_in, noise, n_vis, code, gate.active_capacity_factor(), gate.min_capacity,
             is_uniform)
         self.l_aux = l_aux
-        self.exp_counts = _host_counts(exp_counts, self.blocking_exp_counts)
+        self.exp_counts = self._host_counts(exp_counts)
         self.last_slot = slot  # [S,2] int32 token -> slot map of the latest forward (diagnostics)
         C = xd.shape[0] // E
 
@@ -594,26 +623,3 @@ class MOELayer(nn.Module):
 
 def _accepts_rows(experts: nn.Module) -> bool:
     return getattr(experts, "accepts_rows", False)
-
-
-_graph_host_counts: Dict[Tuple[int, ...], Tensor] = {}
-
-
-def _host_counts(exp_counts: Tensor, blocking: bool) -> Tensor:
-    if torch.cuda.is_current_stream_capturing():
-        # under HIP-graph capture nothing may be allocated on the host: the copy node targets one
-        # pinned buffer per shape, refilled by every replay (eve_amd.graph.GraphedTrainStep)
-        key = tuple(exp_counts.shape)
-        host = _graph_host_counts.get(key)
-        if host is None:
-            raise RuntimeError("eve_amd: run the layer once eagerly before capturing it into a graph")
-        host.copy_(exp_counts, non_blocking=True)
-        return host
-    if blocking:
-        return exp_counts.to("cpu")
-    host = torch.empty(exp_counts.shape, dtype=exp_counts.dtype, pin_memory=True)
-    host.copy_(exp_counts, non_blocking=True)
-    key = tuple(exp_counts.shape)
-    if key not in _graph_host_counts:
-        _graph_host_counts[key] = torch.empty(exp_counts.shape, dtype=exp_counts.dtype, pin_memory=True)
-    return host

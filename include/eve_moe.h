@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 4
+#define EVE_MOE_ABI_VERSION 5
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -54,6 +54,12 @@ enum {
 
 int eve_moe_abi_version(void);
 const char* eve_moe_last_error(void);
+
+/* Hex digest (sha256, first 16 hex digits) of the sources this library was built from: every file of
+ * eve_amd/csrc/ and this header, as computed by eve_amd/build.py::source_hash.  The Python binding recomputes
+ * it from the checkout and refuses a library built from other sources (a stale .so fails loudly instead of
+ * being tested in place of the committed code). */
+const char* eve_moe_source_hash(void);
 
 /* Capacity of one expert queue: max(ceil_f32(f32(S/E) * f32(2*capacity_factor)), min_capacity).
  * Host-only arithmetic.  Replaces _capacity, models/sharded_moe.py:150-160 as called at :177. */
@@ -122,7 +128,8 @@ int eve_gate_top2_fwd_noalloc(const float* logits, const float* noise, int noise
 int eve_gumbel_from_uniform(const float* uniform, float* noise, long n, void* stream);
 
 /* Backward of eve_gate_top2_fwd w.r.t. logits (what autograd derives for :172-235):
- * d_weight [S,2] and d_l_aux [1] (device scalar) in, dlogits [S,E] out. */
+ * d_weight [S,2] and d_l_aux [1] (device scalar) in, dlogits [S,E] out.  Either gradient may be NULL (= zero:
+ * nothing downstream used the combine weights / the auxiliary loss). */
 int eve_gate_top2_bwd(const float* gates, const int32_t* idx, const int32_t* loc, const float* d_weight,
                       const float* d_l_aux, const int64_t* exp_counts, int S, int E, int C, float* dlogits,
                       void* stream);
@@ -176,6 +183,15 @@ int eve_combine_bwd(const void* dout, const void* y, const int32_t* slot, const 
 
 /* ----------------------------------------------------------------------- expert FFNs */
 
+/* `flags` of eve_ffn_fwd / eve_ffn_bwd (no counterpart in the reference, whose experts are stock GEMM calls).
+ * EVE_FFN_SHARED_GPU: the caller runs other work -- the RCCL exchanges of the pipelined expert-parallel path --
+ * on the GPU beside this call's GEMMs, so its launches use one workgroup per output tile, which the dispatcher
+ * places on whichever CUs are free; without it forward / dgrad launches are persistent, one workgroup per CU
+ * walking the tiles, which assumes the whole chip (a CU held by another kernel would push its workgroup into a
+ * second round and double the launch).  A per-call argument: calls on different streams or threads do not
+ * affect each other.  Results are identical either way. */
+enum { EVE_FFN_SHARED_GPU = 1 };
+
 /* Grouped expert FFN forward.  `x` is [G, R, M]: G groups of R rows; group g is processed
  * by local expert g % E_local (so both the single-GPU layout [E, C, M] and the
  * expert-parallel layout [ep, E_local, C, M] of models/sharded_moe.py:370 are covered).
@@ -188,7 +204,7 @@ int eve_combine_bwd(const void* dout, const void* y, const int32_t* slot, const 
  * MultiwayTransformerMLP.forward (models/multiway_transformer.py:51-55). */
 int eve_ffn_fwd(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* z, void* a,
                 void* y, const int32_t* rows, int G, int E_local, int R, int M, int I, int act, int dtype,
-                void* stream);
+                int flags, void* stream);
 
 /* Grouped expert FFN backward.  In: dy [G,R,M] and the tensors of the forward.  Out:
  *   dz  [G,R,I]  scratch (gradient at the pre-activation), dx [G,R,M],
@@ -197,22 +213,14 @@ int eve_ffn_fwd(const void* x, const void* w1, const void* b1, const void* w2, c
  * Rows >= rows[g] contribute nothing and their dx/dz rows are left untouched. */
 int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2,
                 void* dz, void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G,
-                int E_local, int R, int M, int I, int act, int dtype, void* workspace, size_t workspace_bytes,
-                void* stream);
+                int E_local, int R, int M, int I, int act, int dtype, int flags, void* workspace,
+                size_t workspace_bytes, void* stream);
 
 /* Scratch for eve_ffn_bwd (256-byte aligned device memory, contents irrelevant): non-zero only when the two
  * weight-gradient GEMMs are split along K -- few local experts (expert parallelism, the two-group modality
  * split) leave too few output tiles for the CUs; the slices' fp32 partials are then summed in a fixed order. */
 size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype);
 
-/* Process-wide launch policy of eve_ffn_fwd / eve_ffn_bwd (no counterpart in the reference, whose experts are
- * stock GEMM calls).  shared != 0: the caller runs other work -- RCCL exchanges of the pipelined expert-parallel
- * path -- on the GPU beside the GEMMs, so the launches use one workgroup per output tile, which the dispatcher
- * places on whichever CUs are free; shared == 0 (default): forward / dgrad launches are persistent, one workgroup
- * per CU walking the tiles, which assumes the whole chip (a CU held by another kernel would push its workgroup
- * into a second round and double the launch).  Takes effect for launches issued after the call; returns the
- * previous setting.  Results are identical either way. */
-int eve_ffn_set_shared_gpu(int shared);
 
 /* ------------------------------------------------- hard modality split of the non-MoE layers
  * Reference models/multiway_transformer.py:366-370: vision positions [:, :n_vis] go through

@@ -44,7 +44,7 @@ def test_capacity_matches_reference_arithmetic():
 
 def test_argument_errors_are_reported_without_a_gpu():
     lib = _lib.load()
-    rc = lib.eve_ffn_fwd(None, None, None, None, None, None, None, None, None, 1, 1, 1, 8, 8, 0, 0, None)
+    rc = lib.eve_ffn_fwd(None, None, None, None, None, None, None, None, None, 1, 1, 1, 8, 8, 0, 0, 0, None)
     assert rc == -1 and b"null" in lib.eve_moe_last_error()
     with pytest.raises(RuntimeError, match="eve_combine_fwd failed"):
         _lib.call("eve_combine_fwd", None, None, None, None, 1, 8, 0, None)

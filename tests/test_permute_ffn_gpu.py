@@ -136,8 +136,9 @@ def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
 
 
 def test_ffn_shared_gpu_launch_policy_gives_identical_results():
-    """eve_ffn_set_shared_gpu(1): one workgroup per tile instead of persistent workgroups (the pipelined
-    expert-parallel path runs RCCL beside the GEMMs) -- same arithmetic per tile, bit-equal results."""
+    """flags = EVE_FFN_SHARED_GPU: one workgroup per tile instead of persistent workgroups (the pipelined
+    expert-parallel path runs RCCL beside the GEMMs) -- same arithmetic per tile, bit-equal results.  A per-call
+    argument, so calls with and without it may be interleaved freely."""
     from eve_amd import ops, _lib
     G, E_l, R, M, I = 32, 16, 300, 768, 3072  # 768 / 192 forward tiles: more than the 256 CUs, so the default is persistent
     g = torch.Generator().manual_seed(5)
@@ -146,16 +147,14 @@ def test_ffn_shared_gpu_launch_policy_gives_identical_results():
     w1, b1, w2, b2 = mk(E_l, I, M, s=M ** -0.5), mk(E_l, I, s=0.1), mk(E_l, M, I, s=I ** -0.5), mk(E_l, M, s=0.1)
     rows = torch.randint(100, R + 1, (G,), generator=g, dtype=torch.int32).to(DEV)
 
-    def run():
-        z, a, y = ops.ffn_fwd(x, w1, b1, w2, b2, rows, ops.ACTS["quick_gelu"])
-        return (y, a) + tuple(ops.ffn_bwd(dy, x, z, a, w1, w2, rows, ops.ACTS["quick_gelu"]))
+    def run(flag):
+        z, a, y = ops.ffn_fwd(x, w1, b1, w2, b2, rows, ops.ACTS["quick_gelu"], shared_gpu=flag)
+        return (y, a) + tuple(ops.ffn_bwd(dy, x, z, a, w1, w2, rows, ops.ACTS["quick_gelu"], shared_gpu=flag))
 
-    base = run()
-    assert _lib.load().eve_ffn_set_shared_gpu(0) == 0
-    with ops.shared_gpu():
-        shared = run()
-        assert _lib.load().eve_ffn_set_shared_gpu(1) == 1
-    assert _lib.load().eve_ffn_set_shared_gpu(0) == 0  # restored
+    base = run(False)
+    shared = run(True)
+    again = run(False)
+    assert all(torch.equal(p, q) for p, q in zip(base[2:], again[2:]))
     valid = (torch.arange(R, device=DEV)[None, :, None] < rows[:, None, None])
     for k, (p, q) in enumerate(zip(base, shared)):
         if p.dim() == 3 and p.shape[0] == G:  # rows beyond rows[g] are left unwritten

@@ -13,7 +13,7 @@ ap.add_argument("--M", type=int, default=768)
 ap.add_argument("--I", type=int, default=3072)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--fill", type=float, default=0.98)
-ap.add_argument("--shared", action="store_true", help="eve_ffn_set_shared_gpu(1): the launch policy of the pipelined EP path")
+ap.add_argument("--shared", action="store_true", help="flags = EVE_FFN_SHARED_GPU: the launch policy of the pipelined EP path")
 a = ap.parse_args()
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
@@ -26,17 +26,15 @@ b2 = torch.zeros(a.E, a.M, dtype=bf, device=dev)
 dy = torch.randn(a.G, a.R, a.M, generator=g).to(bf).to(dev)
 rows = torch.full((a.G,), int(a.R * a.fill), dtype=torch.int32, device=dev)
 act = ops.ACTS["quick_gelu"]
-if a.shared:
-    ops.shared_gpu().__enter__()
 for it in range(a.iters):
     if it == a.iters - 1:
         torch.cuda.synchronize()
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-    z, aa, y = ops.ffn_fwd(x, w1, b1, w2, b2, rows, act)
+    z, aa, y = ops.ffn_fwd(x, w1, b1, w2, b2, rows, act, shared_gpu=a.shared)
     if it == a.iters - 1:
         e1.record()
-    out = ops.ffn_bwd(dy, x, z, aa, w1, w2, rows, act)
+    out = ops.ffn_bwd(dy, x, z, aa, w1, w2, rows, act, shared_gpu=a.shared)
     if it == a.iters - 1:
         e2.record()
 torch.cuda.synchronize()
