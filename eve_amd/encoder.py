@@ -111,8 +111,10 @@ class MultiwayTransformerEnocderLayer(nn.Module):
             self.num_experts = param.get('num_experts', default_experts)
             self.topk = param.get('topk', default_topk)
             type_route = param.get('type_route', default_route)
+            # 'ep_size' is not a key of the reference's configs (it always builds ep_size = 1, layer.py:54-58 unused):
+            # expert parallelism is opted into through it, experts sharded over torch.distributed's WORLD group
             return MoE(hidden_size=hidden_size, num_experts=self.num_experts, k=self.topk, expert=mlp_tmp,
-                       num_tokens=self.num_vision_tokens if type_route else None)
+                       ep_size=param.get('ep_size', 1), num_tokens=self.num_vision_tokens if type_route else None)
 
         if self.ffn_type == 'moe' and self.use_ffn:
             self.norm2_vl = nn.LayerNorm(hidden_size, eps=1e-6)

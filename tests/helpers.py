@@ -48,3 +48,19 @@ def sparse_pairs(slot, w):
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def assert_close_scaled(got, ref, rtol, atol_frac, name=""):
+    """Per-element |got - ref| <= atol + rtol * |ref| with atol = atol_frac * rms(ref): the tolerance the
+    BASELINE states (rtol 2e-2 for bf16, 1e-5 for fp32) on every element, plus an absolute floor tied to the
+    tensor's own scale for the elements near zero (a norm-wise bound alone leaves small elements unchecked)."""
+    got, ref = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(ref).detach().double().cpu()
+    assert got.shape == ref.shape, (name, tuple(got.shape), tuple(ref.shape))
+    rms = float(ref.pow(2).mean().sqrt())
+    atol = atol_frac * max(rms, 1e-30)
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    if bool(bad.any()):
+        i = int(torch.argmax(err - rtol * ref.abs()))
+        raise AssertionError(f"{name}: {int(bad.sum())} of {bad.numel()} elements outside rtol {rtol} + atol {atol:.3g} "
+                             f"(rms {rms:.3g}); worst: got {float(got.flatten()[i]):.6g} ref {float(ref.flatten()[i]):.6g}")

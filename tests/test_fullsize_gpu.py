@@ -79,6 +79,32 @@ def _sample_check(moe, h, dout, out, dh, ref, aux_w, n_vis, T, E, idx, tol):
     assert worst_g < tol, f"sampled input-gradient error {worst_g}"
 
 
+def _expert_grad_check(moe, h, dout, ref, n_vis, T, E, experts):
+    """dw1 / db1 / dw2 / db2 of a few experts against the CPU oracle's formulae evaluated in fp32 on exactly the
+    rows the (oracle-checked) routing sent to them -- at the full model dims (Large: M = 1024, I = 4096)."""
+    from tests.helpers import assert_close_scaled
+    m = moe.moe
+    f = lambda t: t.detach().float().cpu()
+    S = h.shape[0] * h.shape[1]
+    hs, ds = f(h.reshape(S, -1)), f(dout.reshape(S, -1))
+    ve, te = f(m.vision_embed), f(m.text_embed)
+    pos = torch.arange(S) % T
+    emb = torch.where((pos < n_vis)[:, None], ve[None, :], te[None, :])
+    x = (hs.to(h.dtype) + emb.to(h.dtype)).float()  # what is dispatched: h + modality embedding, rounded to bf16
+    for e in experts:
+        rows, ws = [], []
+        for slot, w in ((ref.slot1, ref.w1), (ref.slot2, ref.w2)):
+            sel = torch.nonzero((slot >= 0) & (torch.div(slot, ref.C, rounding_mode="floor") == e)).flatten()
+            rows.append(sel), ws.append(w[sel])
+        rows, ws = torch.cat(rows), torch.cat(ws)
+        ex = m.experts.experts[e]
+        p = [f(t).requires_grad_(True) for t in (ex.fc1.weight, ex.fc1.bias, ex.fc2.weight, ex.fc2.bias)]
+        y = orc.expert_ffn(x[rows], *p)
+        (y * (ws[:, None] * ds[rows])).sum().backward()
+        for t, q, name in zip((ex.fc1.weight, ex.fc1.bias, ex.fc2.weight, ex.fc2.bias), p, ("dw1", "db1", "dw2", "db2")):
+            assert_close_scaled(t.grad, q.grad, 2e-2, 4e-2, f"expert {e} {name}")
+
+
 @pytest.mark.parametrize("name,M,I,B,n_vis", [("cfg2_base_b64", 768, 3072, 64, 197), ("cfg4_large_vqa480", 1024, 4096, 16, 901),
                                              ("cfg3_large_b32", 1024, 4096, 32, 197)])
 def test_fullsize_train_step_bf16(name, M, I, B, n_vis):
@@ -107,6 +133,7 @@ def test_fullsize_train_step_bf16(name, M, I, B, n_vis):
     np.testing.assert_allclose(l_aux.item(), ref.l_aux.item(), rtol=1e-4)
     idx = torch.randperm(S, generator=g)[:48]
     _sample_check(moe, h, dout, out, dh, ref, 0.5, n_vis, T, E, idx, tol=2e-2)
+    _expert_grad_check(moe, h, dout, ref, n_vis, T, E, experts=(0, 17, 31))
     # determinism + exact linearity of the backward in the upstream gradient (x2 is exact in bf16/fp32)
     out_b, _, dh_b, grads_b = run(1.0)
     assert torch.equal(out, out_b) and torch.equal(dh, dh_b)
@@ -192,3 +219,30 @@ def test_topkgate_dense_compat_matches_reference(gate_cases, name):
     assert np.array_equal(mask.reshape(S, -1).cpu().numpy(), dense != 0)
     assert cnt.device.type == "cpu" and np.array_equal(cnt.numpy(), c["exp_counts"])
     assert cw.shape[2] == int(c["C"])
+
+
+@pytest.mark.parametrize("case", ["first_owns_slot0_second_dropped", "first_dropped_second_owns_slot0"])
+def test_dense_compat_slot0_with_a_dropped_partner(case):
+    """A token that holds slot 0 (expert 0, location 0) while its other choice is over capacity: the dense
+    compatibility tensors must keep its weight at [s, 0, 0] (a dropped choice must not be scattered onto slot 0).
+    Expected: the oracle's dense one-hot formulation (reference sharded_moe.py:172-235)."""
+    from eve_amd.sharded_moe import top2gating
+    S, E = 16, 4  # capacity_factor 0.5 -> C = max(ceil(16 / 4 * 1.0), 4) = 4
+    logits = torch.full((S, E), -4.0)
+    if case == "first_owns_slot0_second_dropped":
+        logits[0, 0], logits[0, 1] = 4.0, 2.0          # token 0: first expert 0 (slot 0), second expert 1 ...
+        logits[1:7, 1], logits[1:7, 2] = 4.0, 2.0      # ... which six later tokens pick first: location 6 >= C
+        logits[7:, 3], logits[7:, 2] = 4.0, 2.0
+        tok = 0
+    else:
+        logits[0:6, 1], logits[0:6, 2] = 4.0, 2.0      # tokens 0-5 pick expert 1 first: tokens 4, 5 are over capacity
+        logits[5, 2], logits[5, 0] = -4.0, 2.0         # token 5: first dropped, second = expert 0, location 0 -> slot 0
+        logits[6:, 3], logits[6:, 2] = 4.0, 2.0
+        tok = 5
+    noise = torch.zeros(S, E)
+    ref_l, ref_cw, ref_mask, ref_cnt = orc.dense_top2gating(logits, noise, 0.5, 4)
+    assert ref_cw.shape[2] == 4 and float(ref_cw[tok, 0, 0]) > 0 and int((ref_cw[tok] != 0).sum()) == 1
+    for _ in range(5):  # a racy scatter would show up on some repetition
+        l_aux, cw, mask, cnt = top2gating(logits.to(DEV), 0.5, 4, noise=noise.to(DEV))
+        torch.testing.assert_close(cw.cpu(), ref_cw, rtol=2e-6, atol=1e-9)
+        assert torch.equal(mask.cpu(), ref_mask) and torch.equal(cnt, ref_cnt)

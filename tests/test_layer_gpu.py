@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import moe_oracle as orc
-from tests.helpers import build_moe, expert_grads, rel_err
+from tests.helpers import assert_close_scaled, build_moe, expert_grads, rel_err
 from tests.test_oracle_golden import LAYER_KEYS, _params
 
 pytestmark = pytest.mark.gpu
@@ -74,11 +74,14 @@ def test_cfg1_full_shape_fp32_vs_reference(layer_cfg1):
     assert np.array_equal(cnt.numpy(), z["exp_counts"])
     o = out.detach().cpu().reshape(B * T, M)
     tok = torch.from_numpy(z["tok_index"])
-    np.testing.assert_allclose(o[tok].numpy(), z["out_slice"], rtol=1e-4, atol=1e-5)
+    # fp32 contract: 1e-5 (BASELINE.json) on every element, with the absolute floor at 1e-5 of the slice's largest
+    # element (a K = 3072 fp32 dot product summed in another order than the CPU GEMM's differs by that much where
+    # the terms cancel)
+    np.testing.assert_allclose(o[tok].numpy(), z["out_slice"], rtol=1e-5, atol=1e-5 * float(np.abs(z["out_slice"]).max()))
     np.testing.assert_allclose(o.double().sum(1).numpy(), z["out_rowsum"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(l_aux.item(), z["l_aux"], rtol=1e-5)
     dh = hd.grad.cpu().reshape(B * T, M)
-    np.testing.assert_allclose(dh[tok].numpy(), z["dh_slice"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dh[tok].numpy(), z["dh_slice"], rtol=1e-5, atol=1e-5 * float(np.abs(z["dh_slice"]).max()))
     # reductions over ~1.9k tokens: compare against the tensor's scale (fp32 tolerance 1e-5, BASELINE.json)
     def close(got, ref, tol=1e-5):
         ref = torch.from_numpy(np.asarray(ref))
@@ -127,16 +130,20 @@ def test_layer_bf16_vs_oracle(mode):
     ro, rl, rc, rr = orc.index_moe_forward(hr, pr, noise, mode=mode, n_vis=n_vis, logits_override=lg)
     ((ro * dout.float()).sum() + rl).backward()
     assert torch.equal(cnt, rc)
-    assert rel_err(out.detach().cpu(), ro.detach()) < 2e-2
-    assert rel_err(hd.grad.cpu(), hr.grad) < 2e-2
-    assert rel_err(moe.moe.gate.wg.weight.grad.cpu(), pr["wg"].grad) < 2e-2
+    # every element within rtol 2e-2 (BASELINE.json) + an absolute floor of 2 % of the tensor's rms for activations
+    # and 4 % for parameter gradients (sums over tokens of products of bf16-stored intermediates -- z, a, dz, dy are
+    # bf16 in HBM where the oracle keeps fp32: per-element sigma ~0.5 % of the rms, and 4 M elements reach 5 sigma)
+    chk = lambda got, ref, name: assert_close_scaled(got, ref, 2e-2, 4e-2 if name.startswith("dw") or name.startswith("db") else 2e-2, name)
+    chk(out, ro, "out")
+    chk(hd.grad, hr.grad, "dh")
+    chk(moe.moe.gate.wg.weight.grad, pr["wg"].grad, "dwg")
     dw1, db1, dw2, db2 = expert_grads(moe, E)
-    assert rel_err(dw1, pr["w1"].grad) < 2e-2 and rel_err(dw2, pr["w2"].grad) < 2e-2
-    assert rel_err(db1, pr["b1"].grad) < 2e-2 and rel_err(db2, pr["b2"].grad) < 2e-2
+    chk(dw1, pr["w1"].grad, "dw1"), chk(dw2, pr["w2"].grad, "dw2")
+    chk(db1, pr["b1"].grad, "db1"), chk(db2, pr["b2"].grad, "db2")
     if mode in ("vl", "vision"):
-        assert rel_err(moe.moe.vision_embed.grad.cpu().float(), pr["vision_embed"].grad) < 2e-2
+        chk(moe.moe.vision_embed.grad, pr["vision_embed"].grad, "dvision_embed")
     if mode in ("vl", "text"):
-        assert rel_err(moe.moe.text_embed.grad.cpu().float(), pr["text_embed"].grad) < 2e-2
+        chk(moe.moe.text_embed.grad, pr["text_embed"].grad, "dtext_embed")
 
 
 def test_state_dict_roundtrip_and_repack():
@@ -185,3 +192,44 @@ def test_rng_replay_matches():
     with torch.no_grad():
         b = moe(h)[0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("use_reentrant", [False, True])
+def test_activation_checkpoint_recompute_replays_the_gumbel_draw(use_reentrant):
+    """The reference re-executes the layer under activation checkpointing (multiway_transformer.py:574-586,
+    fairscale checkpoint_wrapper VQA.py:239): torch's checkpoint stashes and restores the device RNG state, and the
+    layer draws its noise with one torch.rand from the global generator, so the recomputed forward must route
+    exactly like the first one and give the gradients of an un-checkpointed step from the same seed."""
+    from torch.utils.checkpoint import checkpoint
+    M, I, E, B, n_vis, T = 64, 128, 32, 6, 5, 9
+    moe = build_moe(orc.make_params(M, I, E, seed=5), M, I, E, n_vis, device=DEV).train()
+    h0 = orc.synth_hidden(B, T, M, seed=1).to(DEV)
+    dout = torch.randn(B, T, M, generator=torch.Generator().manual_seed(2)).to(DEV)
+    slots = []
+
+    def body(x):
+        out, l_aux, _ = moe(x, mode="vl")
+        slots.append(moe.moe.last_slot.clone())
+        return out, l_aux
+
+    def run(ckpt):
+        for p in moe.parameters():
+            p.grad = None
+        slots.clear()
+        torch.manual_seed(77)
+        x = h0.clone().requires_grad_(True)
+        # (the non-reentrant form stops its recompute as soon as the last saved tensor exists again, which is before
+        # body() records the slots: early stop off, so that the whole forward is re-executed as the reference's does)
+        with torch.utils.checkpoint.set_checkpoint_early_stop(False):
+            out, l_aux = checkpoint(body, x, use_reentrant=use_reentrant) if ckpt else body(x)
+            ((out * dout).sum() + l_aux).backward()
+        torch.cuda.synchronize()
+        return out.detach(), x.grad, [p.grad.clone() for p in moe.parameters()], list(slots)
+
+    out_a, dh_a, g_a, s_a = run(False)
+    out_b, dh_b, g_b, s_b = run(True)
+    assert len(s_a) == 1 and len(s_b) == 2, "the checkpointed step runs the forward twice"
+    assert torch.equal(s_b[0], s_b[1]), "recomputed forward routed differently: the Gumbel draw did not replay"
+    assert torch.equal(s_a[0], s_b[0])
+    assert torch.equal(out_a, out_b) and torch.equal(dh_a, dh_b)
+    assert all(torch.equal(a, b) for a, b in zip(g_a, g_b))
