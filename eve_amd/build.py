@@ -48,13 +48,17 @@ def _stale(out: str) -> bool:
     return any(os.path.getmtime(d) > t for d in source_files())
 
 
-def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False, variant: str = "", defines=()) -> str:
+    """`variant` + `defines`: an experimental build eve_amd/libeve_moe_<variant>.so with extra -D flags and the debug
+    knobs (kernel A/B experiments; select it with EVE_MOE_LIB)."""
     out = OUT_DBG if debug_knobs else OUT
+    if variant:
+        out, debug_knobs = os.path.join(HERE, f"libeve_moe_{variant}.so"), True
     if not force and not _stale(out):
         return out
     digest = source_hash()
     objs = []
-    bdir = os.path.join(HERE, "..", "build", "obj_dbg" if debug_knobs else "obj")
+    bdir = os.path.join(HERE, "..", "build", f"obj_{variant}" if variant else ("obj_dbg" if debug_knobs else "obj"))
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
@@ -67,6 +71,8 @@ def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False) 
             cmd.insert(-4, f'-DEVE_SOURCE_HASH="{digest}"')
         if debug_knobs:
             cmd.insert(-4, "-DEVE_FFN_DEBUG_KNOBS=1")
+        for d in defines:
+            cmd.insert(-4, "-D" + d)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
@@ -81,4 +87,7 @@ def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False) 
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, debug_knobs="--debug-knobs" in sys.argv)
+    argv = sys.argv[1:]
+    var = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
+    defs = [argv[i + 1] for i, a in enumerate(argv) if a == "--define"]
+    build(force="--force" in argv, debug_knobs="--debug-knobs" in argv, variant=var, defines=defs)

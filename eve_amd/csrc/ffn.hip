@@ -248,9 +248,8 @@ extern "C" int eve_ffn_fwd(const void* x, const void* w1, const void* b1, const 
 }
 
 extern "C" size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype) {
-  (void)R;
-  if (G <= 0 || E_local <= 0 || G % E_local != 0 || dtype != EVE_BF16 || !ffn_mfma_supported(M, I)) return 0;
-  return ffn_bwd_mfma_workspace_bytes(G, E_local, M, I);
+  if (G <= 0 || E_local <= 0 || G % E_local != 0 || R <= 0 || dtype != EVE_BF16 || !ffn_mfma_supported(M, I)) return 0;
+  return ffn_bwd_mfma_workspace_bytes(G, E_local, R, M, I);
 }
 
 extern "C" int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2,

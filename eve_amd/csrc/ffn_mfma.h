@@ -13,7 +13,8 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
                  void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G, int E_local, int R,
                  int M, int I, int act, bool shared, void* workspace, size_t workspace_bytes, hipStream_t st);
 
-// bytes of scratch ffn_bwd_mfma needs for these shapes (0 when the weight gradients are not split along K)
-size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int M, int I);
+// bytes of scratch ffn_bwd_mfma needs for these shapes: fp32 partials of the bias gradient db1, plus the split-K
+// partials of the weight gradients when few experts are local
+size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int R, int M, int I);
 
 }  // namespace eve

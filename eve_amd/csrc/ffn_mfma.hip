@@ -77,6 +77,11 @@ struct MfmaDesc {
   int ksplit;
   float* Cpart;
   float* dbias_part;
+  // MEPI_DACT launches: column sums of the OUTPUT (dz) for the bias gradient db1, taken in the epilogue while the
+  // values are in registers: fp32 partials colsum[(z * colsum_slots + slot) * N + n], slot = wave row block of the
+  // group (m0 / rows-per-wave + wave row); colsum_reduce_kernel adds them up in a fixed order.  nullptr = off.
+  float* colsum;
+  int colsum_slots;
 #ifdef EVE_PP_STAMP
   unsigned long long* dbg;  // diagnostic build (tools/pp_stamps.hip): [block 0 / 1000][wave 8][64] cycle stamps (low 32 bits)
   int same_tile;            // diagnostic: every K step fetches K tile 0 (everything hits in L2)
@@ -85,6 +90,7 @@ struct MfmaDesc {
 
 struct MfmaPair {
   MfmaDesc d[2];
+  int nobias;  // weight-gradient launch: no tile takes the bias gradient (it is formed outside, see ffn_bwd_mfma)
   int n0;      // blocks (tiles) of d[0]; a multiple of 8 (the XCD-aware tile order counts from each problem's first block)
   int ntotal;  // tiles of both problems (persistent kernel: the grid is smaller and walks them)
 };
@@ -282,6 +288,26 @@ template <int PER> __device__ __forceinline__ void wait_tiles_in_flight(int tile
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Column sums of a wave's output block for the bias gradient (MEPI_DACT): lane (irow = lane >> 3, ich = lane & 7)
+// holds the sums over its rows of columns ncol .. ncol + 7; the eight row lanes are added by a butterfly (fixed
+// order) and the lanes of row lane 0 store the wave's 64 sums as this (group, slot)'s partial.
+__device__ __forceinline__ void colsum_store(float (&cs)[8], const MfmaDesc& d, int z, int slot, int ncol, int lane) {
+  if (!d.colsum) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = cs[j];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    cs[j] = v;
+  }
+  if (lane < 8) {
+    float* o = d.colsum + ((size_t)z * d.colsum_slots + slot) * d.N + ncol;
+    *reinterpret_cast<float4*>(o) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+  }
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // Epilogue of one block tile.  Per wave, one 32-row slab (MFMA row tile i) at a time through a private
 // fp32 LDS image, so that global stores are 16 B per lane along rows.  Only the wave itself touches
@@ -319,6 +345,9 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
     }
   };
   load_z(0, zbuf[0]);
+  float cs[8];  // DACT: this lane's share of the column sums of the stored values (rows it owns, 8 columns)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     if (i + 1 < WR) load_z(i + 1, zbuf[(i + 1) & 1]);
@@ -366,6 +395,10 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
           const uint32_t* w = &zbuf[i & 1][it].x;
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
+          if (m < mext) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] += v[j];
+          }
         }
         if (m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
       }
@@ -373,6 +406,7 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (EPI == MEPI_DACT) colsum_store(cs, d, z, m0 / (WR * 32) + wm, ncol, lane);
 }
 
 // Epilogue of the plain-store launches on TRANSPOSED accumulators.  With the MFMA operands swapped
@@ -950,7 +984,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp_wgrad(MfmaPair pr) {
   const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
   const int local = bid >> 3, item = (bid & 7) * per_xcd + local;
   if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
-  const bool first_col_tile = (item % tiles_per_group) / tiles_m == 0;
+  const bool first_col_tile = !pr.nobias && (item % tiles_per_group) / tiles_m == 0;
   if (first_col_tile) pp_tile<true, true, EPI, EVE_ACT_IDENTITY, true, true, 32, 4>(pr, smem);
   else pp_tile<true, true, EPI, EVE_ACT_IDENTITY, true, false, 64, 4>(pr, smem);
 #endif
@@ -999,6 +1033,9 @@ __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN],
   };
   load_z(0, zbuf[0]);
   const int c = lane & 31, hh = lane >> 5;
+  float cs[8];  // DACT: this lane's share of the column sums of the stored values
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
 #pragma unroll
   for (int q = 0; q < 2 * WR; ++q) {
     const int i = q >> 1, hv = q & 1;
@@ -1031,6 +1068,10 @@ __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN],
           const uint32_t* w = &zbuf[q & 1][it].x;
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
+          if (m < mext) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] += v[j];
+          }
         }
         if (m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
       }
@@ -1038,6 +1079,7 @@ __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN],
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (EPI == MEPI_DACT) colsum_store(cs, d, z, m0 / (WR * 32) + wm, ncol, lane);
 }
 
 template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
@@ -1186,10 +1228,39 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
   if (h == 1) __builtin_amdgcn_s_barrier();  // interval 0: waves 4-7 have nothing to do yet
   int sl_c = 0;  // ring slot of the A sub-tile of the K step being computed; its B sub-tile is the next slot
   bf16x8 fa[KI][WR], fb[KI][WTN];
+#ifdef EVE_PP_STAMP
+  // diagnostic build (tools/pp_stamps.hip): per tile i < 12, lane 5i+k of stamp_v: k = 0 tile start, 1 K loop done,
+  // 2 epilogue done, 3 barrier(s) behind the epilogue passed; lanes 62 / 63: kernel start (cycles / 100 MHz ticks).
+  // K-step stamps of tile number pr.d[0].same_tile: lane 6t+k of stamp_w, t < 10: k = 0 L start, 1 reads done
+  // (lgkmcnt 0), 2 barrier passed, 3 MFMAs issued, 4 fetch landed (vmcnt 0), 5 barrier passed
+  uint32_t stamp_v = 0, stamp_w = 0;
+  int tile_i = 0;
+#define EVE_KSTAMP(k)                                                              \
+  do {                                                                             \
+    if (tile_i == pr.d[0].same_tile && t < 10) {                                   \
+      const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime();                  \
+      stamp_w = lane == t * 6 + (k) ? c_ : stamp_w;                                \
+    }                                                                              \
+  } while (0)
+#define EVE_PSTAMP(k)                                                              \
+  do {                                                                             \
+    if (tile_i < 12) {                                                             \
+      const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime();                  \
+      stamp_v = lane == tile_i * 5 + (k) ? c_ : stamp_v;                           \
+    }                                                                              \
+  } while (0)
+  { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 62 ? c_ : stamp_v; }
+  { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memrealtime(); stamp_v = lane == 63 ? c_ : stamp_v; }
+#else
+#define EVE_PSTAMP(k) do { } while (0)
+#define EVE_KSTAMP(k) do { } while (0)
+#endif
   for (;;) {
     const MfmaDesc& d = pr.d[cur.which];
     const bool do_bias_grad = BIAS_GRAD && cur.n0 == 0;
+    EVE_PSTAMP(0);
     for (int t = 0; t < cur.nk; ++t) {
+      EVE_KSTAMP(0);
       // ---- L phase
       const char* sa = smem + sl_c * kSub;
       const char* sb = smem + wrap(sl_c + 1) * kSub;
@@ -1236,7 +1307,9 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
       if (BIAS_GRAD && f_valid) fetch_next(wrap(sl_c + 3 + h));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       frag_fence(fa, fb);
+      EVE_KSTAMP(1);
       __builtin_amdgcn_s_barrier();
+      EVE_KSTAMP(2);
       // ---- M phase
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -1250,10 +1323,14 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      EVE_KSTAMP(3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my fetch has landed (it had the whole M phase)
+      EVE_KSTAMP(4);
       if (!(kResync && h == 1 && t == cur.nk - 1)) __builtin_amdgcn_s_barrier();
+      EVE_KSTAMP(5);
       sl_c = wrap(sl_c + 2);
     }
+    EVE_PSTAMP(1);
     // ---- E phase
     // (behind the ring every wave has its own image: after a tile without K steps -- an expert that
     // received no rows -- waves 0-3 are in their next E phase while waves 4-7 are still in this one)
@@ -1303,6 +1380,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     have = advance(gb_c, cur, false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my staging image is free again
+    EVE_PSTAMP(2);
     // waves 4-7 run one phase behind: their last E phase has no partner phase and no barrier
     if (!have) {
       if (h == 0 && !kResync) __builtin_amdgcn_s_barrier();
@@ -1310,7 +1388,20 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
     }
     __builtin_amdgcn_s_barrier();
     if (kResync && h == 1) __builtin_amdgcn_s_barrier();  // the empty phase: waves 0-3 are in the next tile's first L phase
+    EVE_PSTAMP(3);
+#ifdef EVE_PP_STAMP
+    ++tile_i;
+#endif
   }
+#ifdef EVE_PP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 60 ? c_ : stamp_v; }
+  { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memrealtime(); stamp_v = lane == 61 ? c_ : stamp_v; }
+  if (pr.d[0].dbg && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    pr.d[0].dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_v;
+    pr.d[0].dbg[1024 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_w;
+  }
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -1330,6 +1421,67 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
   }
   *reinterpret_cast<uint4*>(out + i) = pack8(v);
+}
+
+// db[e][n] = bf16(sum over the groups g = seg * E_local + e that share expert e and over the wave row blocks
+// ("slots") that the MEPI_DACT launch wrote for g, of part[(g * slots + s) * N + n]); fixed order.  Slots of
+// tiles the launch skipped (first row at or beyond rows[g]) were never written and are not read.
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, bf16_t* __restrict__ out,
+                                                            const int32_t* __restrict__ rows, int G, int E_local, int R,
+                                                            int N, int slots, int tile_rows, int spt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int g = e; g < G; g += E_local) {
+    const int mext = rows ? min(R, rows[g]) : R;
+    const int valid = (mext + tile_rows - 1) / tile_rows * spt;
+    for (int sl = 0; sl < valid; ++sl) acc += part[((size_t)g * slots + sl) * N + n];
+  }
+  out[(size_t)e * N + n] = static_cast<bf16_t>(acc);
+}
+
+// out[e][c] = bf16(sum over the groups g that share expert e and rows r < rows[g] of x[g][r][c]) for a row-major
+// [G, R, N] bf16 tensor: the bias gradient db2 = column sums of dy.  Block = 64 columns (8 chunks of 16 B) x 128
+// row lanes; each thread walks its rows in order (two loads in flight), the row lanes are added through LDS in order.
+__global__ __launch_bounds__(1024) void rows_colsum_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                           const int32_t* __restrict__ rows, int G, int E_local, int R, int N) {
+  __shared__ float red[128][64 + 1];
+  const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3, e = blockIdx.y;
+  const int col = blockIdx.x * 64 + ch * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (col < N) {
+    for (int g = e; g < G; g += E_local) {
+      const int mext = rows ? min(R, rows[g]) : R;
+      const bf16_t* xg = x + (size_t)g * R * N + col;
+      int r = rl;
+      for (; r + 128 < mext; r += 256) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(xg + (size_t)r * N);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(xg + (size_t)(r + 128) * N);
+        const uint32_t *w0 = &v0.x, *w1 = &v1.x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf16_bits_to_f32(w0[j >> 1], j & 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf16_bits_to_f32(w1[j >> 1], j & 1);
+      }
+      if (r < mext) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(xg + (size_t)r * N);
+        const uint32_t* w0 = &v0.x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf16_bits_to_f32(w0[j >> 1], j & 1);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][ch * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float sum = 0.f;
+    for (int r = 0; r < 128; ++r) sum += red[r][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) out[(size_t)e * N + c] = static_cast<bf16_t>(sum);
+  }
 }
 
 bool ffn_mfma_supported(int M, int I) { return M % 256 == 0 && I % 256 == 0; }
@@ -1446,6 +1598,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, co
   MfmaPair pr;
   pr.d[0] = d;
   pr.d[1] = d2 ? *d2 : d;
+  pr.nobias = 0;
   pr.n0 = blocks(d);
   pr.ntotal = pr.n0 + (d2 ? blocks(*d2) : 0);
   // persistent variant: one workgroup per CU walks the tiles (single K segment only).  The activation
@@ -1493,19 +1646,32 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, co
 // fewer row-steps (e.g. 3 column tiles x 948 rows x 32 experts: 480 tiles of 192 rows fill two waves of
 // 256 CUs, where 384 tiles of 256 rows leave the second wave half empty); 128 x 256 tiles (4 waves) when
 // the row extent is small enough that a larger tile would be mostly padding.
-template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
-static int launch(const MfmaDesc& d, int act, hipStream_t st, bool shared) {
+struct TileChoice { int rows, spt; bool pingpong; };  // tile height, wave row blocks per tile, kernel family
+template <bool A_COL, bool WGRAD>
+static TileChoice choose_tile(const MfmaDesc& d) {
   const int force = knobs().tile_rows;  // debug knob: force 128, 192 or 256
   const bool small = !WGRAD && (force == 128 ||
                                 (!force && (d.Mext <= 128 || (d.Mext % 256 != 0 && d.Mext % 256 <= 128 && d.Mext < 1024))));
-  if (small) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
-  if (!use_pingpong()) return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
+  if (small) return {128, 1, false};
+  if (!use_pingpong()) return {256, 2, false};
   if constexpr (!A_COL && !WGRAD) {
     const long cus = cu_count(), per = (long)d.G * (d.N / BN);
     const long cost256 = ceil_div(per * ceil_div(d.Mext, 256), cus) * 256;
     const long cost192 = ceil_div(per * ceil_div(d.Mext, 192), cus) * 192;
     const bool use192 = force ? force == 192 : cost192 * 10 < cost256 * 9;
-    if (use192) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, 64, 3>(d, act, st, shared);
+    if (use192) return {192, 2, true};
+  }
+  return {256, 2, true};
+}
+template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
+static int launch(const MfmaDesc& d, int act, hipStream_t st, bool shared) {
+  const TileChoice tc = choose_tile<A_COL, WGRAD>(d);
+  if (!tc.pingpong) {
+    if (tc.rows == 128) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
+    return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
+  }
+  if constexpr (!A_COL && !WGRAD) {
+    if (tc.rows == 192) return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, 64, 3>(d, act, st, shared);
   }
   return launch_pp<A_COL, B_COL, EPI, WGRAD, BIAS_GRAD, (A_COL && B_COL) ? 32 : 64>(d, act, st, shared);
 }
@@ -1528,7 +1694,7 @@ int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, 
 
 // both weight-gradient GEMMs of a backward pass in one launch of grouped_gemm_pp_wgrad
 template <int EPI>
-static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st) {
+static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st, bool nobias) {
   constexpr int kLds = 5 * 256 * 64 * 2;
   auto blocks = [](const MfmaDesc& q) {
     return 8 * ceil_div(q.E_local * (q.ksplit > 1 ? q.ksplit : 1) * (q.N / BN) * ceil_div(q.Mext, 256), 8);
@@ -1536,6 +1702,7 @@ static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st
   MfmaPair pr;
   pr.d[0] = d;
   pr.d[1] = d2;
+  pr.nobias = nobias ? 1 : 0;
   pr.n0 = blocks(d);
   pr.ntotal = pr.n0 + blocks(d2);
   auto kern = grouped_gemm_pp_wgrad<EPI>;
@@ -1564,15 +1731,36 @@ static int wgrad_ksplit(int G, int E_local, int M, int I) {
   return j;
 }
 
-size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int M, int I) {
+// Bias gradients of the ping-pong path are formed outside the weight-gradient GEMMs (whose bias-gradient tiles had
+// to run a 32-deep body at about half the MFMA rate: a third of the dw1 tiles, a twelfth of the dw2 tiles):
+//   db1 = column sums of dz: partial sums per wave row block, taken in the MEPI_DACT epilogue while dz is in
+//         registers (fp32, before rounding), then colsum_reduce_kernel;
+//   db2 = column sums of dy: rows_colsum_kernel over the (L2 / Infinity-Cache resident) gradient rows.
+// Partial slots per group: one per wave row block; 96 rows is the smallest wave row block of a ping-pong tile.
+static size_t colsum_bytes(int G, int R, int I) { return align_up((size_t)G * (ceil_div(R, 96) + 1) * I * sizeof(float), 256); }
+
+size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int R, int M, int I) {
+  size_t n = use_pingpong() ? colsum_bytes(G, R, I) : 0;
   const int j = wgrad_ksplit(G, E_local, M, I);
-  if (j <= 1) return 0;
-  return (size_t)j * E_local * (2 * (size_t)M * I + M + I) * sizeof(float);
+  if (j > 1) n += (size_t)j * E_local * (2 * (size_t)M * I) * sizeof(float);
+  return n;
 }
 
 int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2, void* dz,
                  void* dx, void* dw1, void* db1, void* dw2, void* db2, const int32_t* rows, int G, int E_local, int R,
                  int M, int I, int act, bool shared, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const bool pp = use_pingpong();
+  const size_t need = ffn_bwd_mfma_workspace_bytes(G, E_local, R, M, I);
+  if (need && (!workspace || workspace_bytes < need)) {
+    set_error("eve_ffn_bwd: workspace %zu < %zu (eve_ffn_bwd_workspace_bytes)", workspace_bytes, need);
+    return EVE_ERR_WORKSPACE;
+  }
+  if (need && ((uintptr_t)workspace & 255) != 0) {
+    set_error("eve_ffn_bwd: workspace must be 256-byte aligned");
+    return EVE_ERR_ARG;
+  }
+  float* colsum = pp ? static_cast<float*>(workspace) : nullptr;
+  float* ksplit_ws = pp ? reinterpret_cast<float*>(static_cast<char*>(workspace) + colsum_bytes(G, R, I)) : nullptr;
   MfmaDesc d{};
   d.G = G; d.E_local = E_local; d.rows = rows;
   // dz = (dy @ w2) * act'(z): A = dy [R,M] row-major, B = w2 [M,I] k-major
@@ -1580,7 +1768,26 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   d.A = (const bf16_t*)dy; d.a_g = (long)R * M; d.lda = M;
   d.B = (const bf16_t*)w2; d.b_g = (long)M * I; d.ldb = I;
   d.C = (bf16_t*)dz; d.c_g = (long)R * I; d.ldc = I; d.Zin = (const bf16_t*)z; d.N = I; d.K = M;
+  const TileChoice tc = choose_tile<false, false>(d);
+  const int wave_rows = tc.rows / tc.spt;
+  if (pp) {
+    d.colsum = colsum;
+    d.colsum_slots = ceil_div(R, tc.rows) * tc.spt;
+    if ((size_t)G * d.colsum_slots * I * sizeof(float) > colsum_bytes(G, R, I)) {
+      set_error("eve_ffn_bwd: internal: column-sum partials exceed their workspace (tile %d rows)", tc.rows);
+      return EVE_ERR_WORKSPACE;
+    }
+  }
+  (void)wave_rows;
   if (int rc = launch<false, true, MEPI_DACT, false, false>(d, act, st, shared)) return rc;
+  if (pp) {  // db1 from the partials, db2 from dy
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(I, 256), E_local), dim3(256), 0, st, colsum, (bf16_t*)db1, rows, G,
+                       E_local, R, I, d.colsum_slots, tc.rows, tc.spt);
+    hipLaunchKernelGGL(rows_colsum_kernel, dim3(ceil_div(M, 64), E_local), dim3(1024), 0, st, (const bf16_t*)dy, (bf16_t*)db2,
+                       rows, G, E_local, R, M);
+    EVE_CHECK_LAUNCH("colsum_reduce_kernel / rows_colsum_kernel");
+  }
+  d.colsum = nullptr;
   // dx = dz @ w1: A = dz [R,I] row-major, B = w1 [I,M] k-major
   d.A = (const bf16_t*)dz; d.a_g = (long)R * I; d.lda = I;
   d.B = (const bf16_t*)w1; d.b_g = (long)I * M; d.ldb = M;
@@ -1597,34 +1804,24 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   d1.A = (const bf16_t*)dz; d1.a_g = (long)R * I; d1.lda = I;
   d1.B = (const bf16_t*)x; d1.b_g = (long)R * M; d1.ldb = M;
   d1.C = (bf16_t*)dw1; d1.c_g = (long)I * M; d1.ldc = M; d1.N = M; d1.K = R; d1.dbias = (bf16_t*)db1;
-  if (use_pingpong()) {
+  if (pp) {
     const int ks = wgrad_ksplit(G, E_local, M, I);
     if (ks > 1) {
-      const size_t need = ffn_bwd_mfma_workspace_bytes(G, E_local, M, I);
-      if (!workspace || workspace_bytes < need) {
-        set_error("eve_ffn_bwd: workspace %zu < %zu (eve_ffn_bwd_workspace_bytes)", workspace_bytes, need);
-        return EVE_ERR_WORKSPACE;
-      }
       const size_t nw = (size_t)E_local * M * I;
-      float* ws = static_cast<float*>(workspace);
-      float* p_dw2 = ws;                       // [ks][E_local][M][I]
+      float* p_dw2 = ksplit_ws;                // [ks][E_local][M][I]
       float* p_dw1 = p_dw2 + ks * nw;          // [ks][E_local][I][M]
-      float* p_db2 = p_dw1 + ks * nw;          // [ks][E_local][M]
-      float* p_db1 = p_db2 + (size_t)ks * E_local * M;  // [ks][E_local][I]
-      d.ksplit = ks; d.Cpart = p_dw2; d.dbias_part = p_db2;
-      d1.ksplit = ks; d1.Cpart = p_dw1; d1.dbias_part = p_db1;
-      if (int rc = launch_pp_wgrad<MEPI_STORE_F32>(d, d1, st)) return rc;
+      d.ksplit = ks; d.Cpart = p_dw2; d.dbias_part = nullptr;
+      d1.ksplit = ks; d1.Cpart = p_dw1; d1.dbias_part = nullptr;
+      if (int rc = launch_pp_wgrad<MEPI_STORE_F32>(d, d1, st, true)) return rc;
       auto reduce = [&](const float* part, void* out, size_t n) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, part, (bf16_t*)out, n, n, ks);
       };
       reduce(p_dw2, dw2, nw);
       reduce(p_dw1, dw1, nw);
-      reduce(p_db2, db2, (size_t)E_local * M);
-      reduce(p_db1, db1, (size_t)E_local * I);
       EVE_CHECK_LAUNCH("wgrad_reduce_kernel");
       return EVE_OK;
     }
-    if (!knobs().wgrad32) return launch_pp_wgrad<MEPI_STORE>(d, d1, st);  // one launch for both GEMMs
+    if (!knobs().wgrad32) return launch_pp_wgrad<MEPI_STORE>(d, d1, st, true);  // one launch for both GEMMs
     return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, shared, &d1);  // debug knob: all tiles 32 deep (persistent)
   }
   if (int rc = launch<true, true, MEPI_STORE, true, true>(d, act, st, shared)) return rc;

@@ -216,9 +216,11 @@ int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, con
                 int E_local, int R, int M, int I, int act, int dtype, int flags, void* workspace,
                 size_t workspace_bytes, void* stream);
 
-/* Scratch for eve_ffn_bwd (256-byte aligned device memory, contents irrelevant): non-zero only when the two
- * weight-gradient GEMMs are split along K -- few local experts (expert parallelism, the two-group modality
- * split) leave too few output tiles for the CUs; the slices' fp32 partials are then summed in a fixed order. */
+/* Scratch for eve_ffn_bwd (256-byte aligned device memory, contents irrelevant).  bf16 MFMA path: fp32 partial
+ * column sums of dz, taken in the epilogue of the GEMM that produces dz and reduced in a fixed order to db1 (the
+ * bias gradients are formed outside the weight-gradient GEMMs), plus -- when the two weight-gradient GEMMs are split
+ * along K because few local experts (expert parallelism, the two-group modality split) leave too few output tiles
+ * for the CUs -- the slices' fp32 partials, summed in a fixed order.  0 for the fp32 path. */
 size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype);
 
 

@@ -149,7 +149,8 @@ def test_grouped_ffn_bf16_model_dims_and_split_k(G, E_l, R, M, I, use_rows):
     from eve_amd import _lib
     want_split = {(768, 1): 4, (768, 2): 2, (768, 4): 1, (1024, 1): 2, (1024, 2): 1, (1024, 4): 1}[(M, E_l)]
     nbytes = _lib.load().eve_ffn_bwd_workspace_bytes(G, E_l, R, M, I, _lib.BF16)
-    assert nbytes == (0 if want_split == 1 else want_split * E_l * (2 * M * I + M + I) * 4)
+    colsum = -(-(G * (-(-R // 96) + 1) * I * 4) // 256) * 256   # fp32 partials of db1, one slot per wave row block
+    assert nbytes == colsum + (0 if want_split == 1 else want_split * E_l * 2 * M * I * 4)
     test_grouped_ffn_fwd_bwd(torch.bfloat16, G, E_l, R, M, I, use_rows)
 
 

@@ -13,6 +13,7 @@ ap.add_argument("--M", type=int, default=768)
 ap.add_argument("--I", type=int, default=3072)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--fill", type=float, default=0.98)
+ap.add_argument("--act", default="quick_gelu")
 ap.add_argument("--shared", action="store_true", help="flags = EVE_FFN_SHARED_GPU: the launch policy of the pipelined EP path")
 a = ap.parse_args()
 dev = "cuda:0"
@@ -25,7 +26,7 @@ w2 = (torch.randn(a.E, a.M, a.I, generator=g) * 0.02).to(bf).to(dev)
 b2 = torch.zeros(a.E, a.M, dtype=bf, device=dev)
 dy = torch.randn(a.G, a.R, a.M, generator=g).to(bf).to(dev)
 rows = torch.full((a.G,), int(a.R * a.fill), dtype=torch.int32, device=dev)
-act = ops.ACTS["quick_gelu"]
+act = ops.ACTS[a.act]
 for it in range(a.iters):
     if it == a.iters - 1:
         torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 // Diagnostic build of the ping-pong grouped GEMM with in-kernel cycle stamps (s_memtime) around the
 // L / M phases of the first K tiles of two workgroups.  Not part of the library.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Ieve_amd/csrc -DEVE_PP_STAMP \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Ieve_amd/csrc -DEVE_PP_STAMP -Wno-unused-const-variable \
 //         tools/pp_stamps.hip eve_amd/csrc/capi.hip -o tools/pp_stamps
 #include <cstdio>
 #include <cstdlib>
@@ -30,11 +30,11 @@ static void run(const char* name, int G, int R, int N, int K, bool bcol, int sam
   d.B = B; d.b_g = (long)N * K; d.ldb = bcol ? N : K;
   d.C = C; d.C2 = C; d.c_g = (long)R * N; d.ldc = N; d.bias = bias; d.Zin = Z; d.N = N; d.K = K;
   d.dbg = nullptr; d.same_tile = same_tile;
-  for (int i = 0; i < 20; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, EVE_ACT_QUICK_GELU, 0);
+  for (int i = 0; i < 20; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, EVE_ACT_QUICK_GELU, 0, false);
   hipDeviceSynchronize();
   hipMemset(dbg, 0, 2 * 8 * 64 * 8);
   d.dbg = dbg;
-  launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, EVE_ACT_QUICK_GELU, 0);
+  launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, EVE_ACT_QUICK_GELU, 0, false);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(2 * 8 * 64);
   hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
@@ -59,7 +59,76 @@ static void run(const char* name, int G, int R, int N, int K, bool bcol, int sam
   hipFree(A); hipFree(B); hipFree(C); hipFree(Z); hipFree(bias); hipFree(dbg);
 }
 
-int main() {
+// persistent kernel (grouped_gemm_ppp): per-tile timeline of two workgroups, waves 0 and 4, and the clock held
+template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BG, int BKI, int WR = 4>
+static void run_p(const char* name, int G, int R, int N, int K, bool bcol, int act, int ktile = 2) {
+  const size_t na = (size_t)G * R * K, nb = (size_t)G * N * K, nc = (size_t)G * R * N;
+  std::vector<unsigned short> ha(na), hb(nb);
+  srand(1);
+  for (auto& v : ha) v = 0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15);
+  for (auto& v : hb) v = 0x3a00 + (rand() & 0x3ff) + ((rand() & 1) << 15);
+  bf16_t *A, *B, *C, *C2, *bias, *Z;
+  unsigned long long* dbg;
+  hipMalloc(&A, na * 2); hipMalloc(&B, nb * 2); hipMalloc(&C, nc * 2); hipMalloc(&C2, nc * 2); hipMalloc(&Z, nc * 2); hipMalloc(&bias, (size_t)G * N * 2);
+  hipMalloc(&dbg, 2 * 2 * 8 * 64 * 8);
+  hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice);
+  hipMemcpy(B, hb.data(), nb * 2, hipMemcpyHostToDevice);
+  hipMemset(bias, 0, (size_t)G * N * 2); hipMemset(Z, 0, nc * 2);
+  MfmaDesc d{};
+  d.G = G; d.E_local = G; d.rows = nullptr; d.Mext = R;
+  d.A = A; d.a_g = (long)R * K; d.lda = A_COL ? R : K;
+  d.B = B; d.b_g = (long)N * K; d.ldb = bcol ? N : K;
+  d.C = C; d.C2 = C2; d.c_g = (long)R * N; d.ldc = N; d.bias = bias; d.Zin = Z; d.N = N; d.K = K;
+  d.dbg = nullptr; d.same_tile = ktile;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 200; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, act, 0, false);  // reach the steady clock
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < 50; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, act, 0, false);
+  hipEventRecord(e1, 0);
+  hipMemset(dbg, 0, 2 * 2 * 8 * 64 * 8);
+  d.dbg = dbg;
+  launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, act, 0, false);
+  hipDeviceSynchronize();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(2 * 2 * 8 * 64);
+  hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+  auto df = [](unsigned long long x, unsigned long long y) { return (long long)(int)((unsigned)x - (unsigned)y); };
+  printf("== persistent %s  G=%d R=%d N=%d K=%d act=%d: %.1f us per launch (%s)\n", name, G, R, N, K, act, ms * 1000 / 50, hipGetErrorString(hipGetLastError()));
+  for (int b = 0; b < 2; ++b)
+    for (int w = 0; w < 8; w += 4) {
+      const unsigned long long* s = &h[(b * 8 + w) * 64];
+      const double clk = (double)df(s[60], s[62]) / (double)df(s[61], s[63]) * 100.0;  // MHz
+      printf(" block %d wave %d: whole kernel %lld cycles, clock %.0f MHz\n", b ? 100 : 0, w, df(s[60], s[62]), clk);
+      for (int i = 0; i < 8; ++i) {
+        const unsigned long long* q = s + 5 * i;
+        if (!q[0] && !q[1]) break;
+        printf("   tile %d: start %7lld | K loop %6lld | epilogue %6lld | barrier %6lld | -> next start %6lld\n", i, df(q[0], s[62]), df(q[1], q[0]),
+               df(q[2], q[1]), df(q[3], q[2]), q[5] ? df(q[5], q[3]) : 0LL);
+      }
+      if (b == 0) {
+        const unsigned long long* k = &h[1024 + (b * 8 + w) * 64];
+        printf("   K steps of tile %d:  L(reads) | barrier | M(issue) | vmcnt0 | barrier\n", ktile);
+        for (int t = 0; t < 10; ++t) {
+          const unsigned long long* q = k + 6 * t;
+          if (!q[0]) break;
+          printf("     t=%2d  %5lld | %5lld | %5lld | %5lld | %5lld\n", t, df(q[1], q[0]), df(q[2], q[1]), df(q[3], q[2]), df(q[4], q[3]), df(q[5], q[4]));
+        }
+      }
+    }
+  hipFree(A); hipFree(B); hipFree(C); hipFree(C2); hipFree(Z); hipFree(bias); hipFree(dbg);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) {  // persistent-kernel timelines
+    run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act", 32, 948, 3072, 768, false, EVE_ACT_QUICK_GELU);
+    run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act, K steps of tile 0", 32, 948, 3072, 768, false, EVE_ACT_QUICK_GELU, 0);
+    run_p<false, true, MEPI_DACT, false, false, 64>("dgrad2 act'", 32, 948, 3072, 768, true, EVE_ACT_QUICK_GELU);
+    run_p<false, false, MEPI_BIAS, false, false, 64, 3>("fwd2 192-row", 32, 948, 768, 3072, false, EVE_ACT_QUICK_GELU);
+    run_p<false, true, MEPI_STORE, false, false, 64, 3>("dgrad1 192-row", 32, 948, 768, 3072, true, EVE_ACT_QUICK_GELU);
+    return 0;
+  }
   run<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1  (row,row) N=3072 K=768, bias + quick_gelu epilogue", 32, 948, 3072, 768, false);
   run<false, true, MEPI_DACT, false, false, 64>("dgrad2 (row,col) N=3072 K=768, act' epilogue", 32, 948, 3072, 768, true);
   run<false, false, MEPI_BIAS, false, false, 64>("fwd2  (row,row) N=768 K=3072, 256-row tiles", 32, 948, 768, 3072, false);
