@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("EVE_MOE_LIB", LIB_PATH)  # A/B experiments: an altern
 F32, BF16 = 0, 1
 MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3
 ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 FFN_SHARED_GPU = 1
 
 _P, _I, _Z = c_void_p, c_int, c_size_t
@@ -50,7 +50,20 @@ SIGNATURES = {
     "eve_ffn_fwd": (c_int, [_P] * 9 + [_I] * 8 + [_P]),
     "eve_ffn_bwd": (c_int, [_P] * 13 + [_I] * 8 + [_P, _Z, _P]),
     "eve_ffn_bwd_workspace_bytes": (c_size_t, [_I] * 6),
+    "eve_moe_saved_bytes": (c_size_t, [_P, _I]),
+    "eve_moe_workspace_bytes": (c_size_t, [_P, _I]),
+    "eve_moe_saved_offsets": (c_int, [_P, _I, _P, _I]),
+    "eve_moe_fwd": (c_int, [_P] * 6 + [_I] + [_P] * 7 + [_Z, _I, _P, _Z, _P]),
+    "eve_moe_bwd": (c_int, [_P] * 10 + [_Z] + [_P] * 9 + [_Z, _P]),
 }
+MOE_PASS_INFERENCE, MOE_PASS_FORWARD, MOE_PASS_BACKWARD = 0, 1, 2
+MOE_SAVED_FIELDS = ("gates", "idx", "loc", "slot", "weight", "slot_token", "slot_weight", "rows", "exp_counts",
+                    "xd", "z", "a", "y")
+
+
+class MoEShape(ctypes.Structure):
+    """`eve_moe_shape` of include/eve_moe.h."""
+    _fields_ = [(n, c_int) for n in ("S", "T", "n_vis", "mode", "M", "I", "E", "C", "act", "dtype", "embed_dtype")]
 
 _lib = None
 

@@ -384,6 +384,120 @@ class _CombineFn(torch.autograd.Function):
         return dy, dw, None, None, None
 
 
+_fused_plans: Dict[tuple, tuple] = {}
+
+
+def _fused_plan(key: tuple):
+    """(shape struct, {pass: workspace bytes}, {need_backward: (saved bytes, offsets)}) of one layer shape."""
+    plan = _fused_plans.get(key)
+    if plan is None:
+        import ctypes
+        lib = _lib.load()
+        shape = _lib.MoEShape(*key)
+        ref = ctypes.addressof(shape)
+        ws = {p: int(lib.eve_moe_workspace_bytes(ref, p)) for p in
+              (_lib.MOE_PASS_INFERENCE, _lib.MOE_PASS_FORWARD, _lib.MOE_PASS_BACKWARD)}
+        saved = {}
+        n = len(_lib.MOE_SAVED_FIELDS)
+        for nb in (0, 1):
+            offs = (ctypes.c_size_t * n)()
+            _lib.call("eve_moe_saved_offsets", ref, nb, ctypes.addressof(offs), n)
+            saved[nb] = (int(lib.eve_moe_saved_bytes(ref, nb)), dict(zip(_lib.MOE_SAVED_FIELDS, list(offs))))
+        plan = _fused_plans[key] = (shape, ref, ws, saved)
+    return plan
+
+
+class _FusedMoEFn(torch.autograd.Function):
+    """The whole single-rank layer, one C call per direction (eve_moe_fwd / eve_moe_bwd): reference
+    sharded_moe.py:345-381 with every expert local.  Same kernels, order and results as the per-stage Functions
+    above (`_RouteDispatchFn` -> `_GroupedFFNFn` -> `_CombineFn`); the intermediates live in one `saved` buffer
+    and one workspace per call instead of about twenty separately allocated tensors."""
+
+    @staticmethod
+    def forward(ctx, h, wg, vemb, temb, noise, w1, b1, w2, b2, n_vis, mode, cap_factor, min_capacity,  # type: ignore[override]
+                noise_is_uniform, act, grad_mode):
+        B, T, M = h.shape
+        S = B * T
+        h2d = h.contiguous().view(S, M)
+        wg32 = wg.float().contiguous()
+        ve = None if vemb is None else vemb.to(h.dtype).contiguous()
+        te = None if temb is None else temb.to(h.dtype).contiguous()
+        noise = noise.contiguous()
+        E, I = wg32.shape[0], w1.shape[1]
+        for t, n in ((w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (ve, "vision_embed"), (te, "text_embed")):
+            ops._chk(t, n, h.dtype)
+        ops._chk(h2d, "hidden"), ops._chk(wg32, "wg", torch.float32), ops._chk(noise, "noise", torch.float32)
+        if w1.shape != (E, I, M) or w2.shape != (E, M, I) or b1.shape != (E, I) or b2.shape != (E, M) \
+                or noise.shape != (S, E) or wg32.shape[1] != M:
+            raise RuntimeError("eve_amd: expert / gate parameter shapes do not match the layer input")
+        C = ops.capacity(S, E, cap_factor, min_capacity)
+        v_dt = None if vemb is None else vemb.dtype
+        t_dt = None if temb is None else temb.dtype
+        e_dt = v_dt if v_dt is not None else t_dt
+        fused_dt = e_dt if e_dt in (torch.float32, torch.bfloat16) and v_dt in (None, e_dt) and t_dt in (None, e_dt) \
+            else torch.float32
+        need_bwd = bool(grad_mode and any(ctx.needs_input_grad))
+        key = (S, T, n_vis, mode, M, I, E, C, act, ops._dt(h2d), ops._DTYPES[fused_dt])
+        _, ref, ws_bytes, saved_plan = _fused_plan(key)
+        nbytes, offs = saved_plan[1 if need_bwd else 0]
+        dev = h.device
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nws = ws_bytes[_lib.MOE_PASS_FORWARD if need_bwd else _lib.MOE_PASS_INFERENCE]
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, T, M, dtype=h.dtype, device=dev)
+        l_aux = torch.empty((), dtype=torch.float32, device=dev)
+        ops.PROFILE.call("eve_moe_fwd", ref, ops._p(h2d), ops._p(ve), ops._p(te), ops._p(wg32), ops._p(noise),
+                         1 if noise_is_uniform else 0, ops._p(w1), ops._p(b1), ops._p(w2), ops._p(b2), ops._p(out),
+                         ops._p(l_aux), ops._p(blob), nbytes, 1 if need_bwd else 0, ops._p(ws), nws, ops._stream())
+        o = offs["slot"]
+        slot = blob[o:o + S * 8].view(torch.int32).view(S, 2)
+        o = offs["exp_counts"]
+        exp_counts = blob[o:o + E * 8].view(torch.int64)
+        if need_bwd:
+            ctx.save_for_backward(h2d, wg32, ve, te, w1, w2, blob)
+            ctx.key, ctx.dims = key, (B, T, M, E, I)
+            ctx.param_dtypes = (wg.dtype, v_dt, t_dt, fused_dt)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(slot, exp_counts)
+        return out, l_aux, slot, exp_counts
+
+    @staticmethod
+    def backward(ctx, dout, d_l_aux, *unused):  # type: ignore[override]
+        h2d, wg32, ve, te, w1, w2, blob = ctx.saved_tensors
+        B, T, M, E, I = ctx.dims
+        S = B * T
+        mode = ctx.key[3]
+        _, ref, ws_bytes, _ = _fused_plan(ctx.key)
+        dev, dt = h2d.device, h2d.dtype
+        wg_dt, v_dt, t_dt, fused_dt = ctx.param_dtypes
+        dout = torch.zeros(S, M, dtype=dt, device=dev) if dout is None else dout.contiguous()
+        ops._chk(dout, "dout", dt)
+        dl = None if d_l_aux is None else d_l_aux.reshape(1).float().contiguous()
+        need = ctx.needs_input_grad
+        want_v = mode in (_lib.MODE_VL, _lib.MODE_VISION) and need[2]
+        want_t = mode in (_lib.MODE_VL, _lib.MODE_TEXT) and need[3]
+        dh = torch.empty(B, T, M, dtype=dt, device=dev)
+        dwg = torch.empty(E, M, dtype=torch.float32, device=dev) if need[1] else None
+        dv = torch.empty(M, dtype=fused_dt, device=dev) if want_v else None
+        dte = torch.empty(M, dtype=fused_dt, device=dev) if want_t else None
+        dw1 = torch.empty(E, I, M, dtype=dt, device=dev)
+        db1 = torch.empty(E, I, dtype=dt, device=dev)
+        dw2 = torch.empty(E, M, I, dtype=dt, device=dev)
+        db2 = torch.empty(E, M, dtype=dt, device=dev)
+        nws = ws_bytes[_lib.MOE_PASS_BACKWARD]
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        ops.PROFILE.call("eve_moe_bwd", ref, ops._p(dout), ops._p(dl), ops._p(h2d), ops._p(ve), ops._p(te), ops._p(wg32),
+                         ops._p(w1), ops._p(w2), ops._p(blob), blob.numel(), ops._p(dh), ops._p(dwg), ops._p(dv),
+                         ops._p(dte), ops._p(dw1), ops._p(db1), ops._p(dw2), ops._p(db2), ops._p(ws), nws, ops._stream())
+        if dwg is not None and dwg.dtype != wg_dt:
+            dwg = dwg.to(wg_dt)
+        if dv is not None and dv.dtype != v_dt:
+            dv = dv.to(v_dt)
+        if dte is not None and dte.dtype != t_dt:
+            dte = dte.to(t_dt)
+        return (dh, dwg, dv, dte, None, dw1, db1, dw2, db2) + (None,) * 7
+
+
 # -------------------------------------------------------------------------- functional
 def top2gating(logits: Tensor, capacity_factor: float, min_capacity: int,
                noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
@@ -512,6 +626,9 @@ class MOELayer(nn.Module):
         # asynchronously into a pinned buffer (no host sync per layer) and is valid once the stream has been
         # synchronised.  Under HIP-graph capture the copy node targets a pinned buffer owned by THIS layer.
         self.blocking_exp_counts = True
+        # ep_size == 1: issue the layer as one C call per direction (eve_moe_fwd / eve_moe_bwd).  False = one call
+        # per stage (same kernels and results; what the per-call HIP-event profile of bench.py times).
+        self.fused_call = True
         self._graph_counts_host: Optional[Tensor] = None
         self.l_aux = None
         self.exp_counts = None
@@ -590,6 +707,19 @@ class MOELayer(nn.Module):
             raise NotImplementedError("eve_amd.MOELayer: noisy_gate_policy='Jitter' is not used by EVE and is only "
                                       "supported through TopKGate.forward")
         n_vis = int(self.num_vision_tokens) if has_embed else 0
+
+        if (self.ep_size == 1 and self.fused_call and not ops.PROFILE.on
+                and getattr(self.experts, "packed_parameters", None) is not None and E == self.num_local_experts
+                and E <= 32):
+            # every expert is local: the whole layer is one C call per direction (eve_moe_fwd / eve_moe_bwd)
+            w1, b1, w2, b2 = self.experts.packed_parameters(h.dtype)
+            out, l_aux, slot, exp_counts = _FusedMoEFn.apply(
+                h, gate.wg.weight, vemb_in, temb_in, noise, w1, b1, w2, b2, n_vis, code, gate.active_capacity_factor(),
+                gate.min_capacity, is_uniform, self.experts._act_code, torch.is_grad_enabled())
+            self.l_aux = l_aux
+            self.exp_counts = self._host_counts(exp_counts)
+            self.last_slot = slot
+            return out.view(orig_shape)
 
         xd, weight, l_aux, slot, slot_token, slot_weight, rows, exp_counts = _RouteDispatchFn.apply(
             h, gate.wg.weight, vemb_in, temb_in, noise, n_vis, code, gate.active_capacity_factor(), gate.min_capacity,

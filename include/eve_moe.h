@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 5
+#define EVE_MOE_ABI_VERSION 6
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -223,6 +223,79 @@ int eve_ffn_bwd(const void* dy, const void* x, const void* z, const void* a, con
  * for the CUs -- the slices' fp32 partials, summed in a fixed order.  0 for the fp32 path. */
 size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int dtype);
 
+/* ------------------------------------------------------------- the whole layer in one call per direction
+ *
+ * MOELayer.forward on ONE rank (ep_size == 1: every expert local), models/sharded_moe.py:345-381 over
+ * TopKGate.forward (:283-297), top2gating (:172-235) and Experts.forward (models/experts.py:18-28), and what
+ * autograd derives from them for the backward.  eve_moe_fwd / eve_moe_bwd enqueue exactly the kernels of the
+ * per-stage entry points above, in the same order with the same arguments (results are bit-identical to calling
+ * those one by one); every intermediate lives in two caller-provided buffers, so a host binding pays two foreign
+ * calls and a handful of allocations per step instead of about twenty-five of each.
+ *
+ *   saved      eve_moe_saved_bytes(shape, need_backward): what outlives the forward -- the routing tensors of
+ *              eve_gate_top2_fwd (always) and, when a backward will follow, xd / z / a / y.  The caller keeps it
+ *              untouched until eve_moe_bwd has run.  eve_moe_saved_offsets gives the byte offset of each tensor
+ *              inside it (EVE_MOE_SAVED_*), for callers that want `slot`, `exp_counts`, ... .
+ *   workspace  eve_moe_workspace_bytes(shape, pass): scratch of ONE call (logits, gate scratch, dy / dz / dxd,
+ *              dlogits, the reductions' partials); contents irrelevant before, garbage after.
+ * Both 256-byte aligned device memory.  Expert-parallel layers (ep_size > 1) have a collective between dispatch and
+ * the FFNs and use the per-stage entry points. */
+typedef struct eve_moe_shape {
+  int S;           /* tokens B*T                                                                       */
+  int T;           /* tokens per sample (modality split of mode VL); ignored for EVE_MODE_NONE          */
+  int n_vis;       /* vision tokens per sample (MOELayer.num_vision_tokens)                             */
+  int mode;        /* EVE_MODE_*                                                                        */
+  int M, I;        /* model / expert hidden width                                                       */
+  int E;           /* experts (all local)                                                               */
+  int C;           /* capacity: eve_capacity(S, E, capacity_factor, min_capacity)                       */
+  int act;         /* EVE_ACT_*                                                                         */
+  int dtype;       /* activations, expert weights, modality embeddings                                  */
+  int embed_dtype; /* element type the modality-embedding GRADIENTS are stored as (eve_route_bwd)       */
+} eve_moe_shape;
+
+enum { EVE_MOE_PASS_INFERENCE = 0, EVE_MOE_PASS_FORWARD = 1, EVE_MOE_PASS_BACKWARD = 2 };
+
+/* order of eve_moe_saved_offsets' output; the last four exist only with need_backward (offset (size_t)-1 otherwise) */
+enum {
+  EVE_MOE_SAVED_GATES = 0,   /* [S,E] f32  */
+  EVE_MOE_SAVED_IDX,         /* [S,2] i32  */
+  EVE_MOE_SAVED_LOC,         /* [S,2] i32  */
+  EVE_MOE_SAVED_SLOT,        /* [S,2] i32  */
+  EVE_MOE_SAVED_WEIGHT,      /* [S,2] f32  */
+  EVE_MOE_SAVED_SLOT_TOKEN,  /* [E*C] i32  */
+  EVE_MOE_SAVED_SLOT_WEIGHT, /* [E*C] f32  */
+  EVE_MOE_SAVED_ROWS,        /* [E]   i32  */
+  EVE_MOE_SAVED_EXP_COUNTS,  /* [E]   i64  */
+  EVE_MOE_SAVED_XD,          /* [E*C,M]    */
+  EVE_MOE_SAVED_Z,           /* [E*C,I]    */
+  EVE_MOE_SAVED_A,           /* [E*C,I]    */
+  EVE_MOE_SAVED_Y,           /* [E*C,M]    */
+  EVE_MOE_SAVED_FIELDS
+};
+
+size_t eve_moe_saved_bytes(const eve_moe_shape* shape, int need_backward);
+size_t eve_moe_workspace_bytes(const eve_moe_shape* shape, int pass);
+int eve_moe_saved_offsets(const eve_moe_shape* shape, int need_backward, size_t* offsets, int n_offsets);
+
+/* out [S,M] and l_aux [1] of MOELayer.forward (:345-381): eve_gate_logits_fwd -> eve_gate_top2_fwd ->
+ * eve_dispatch_fwd -> eve_ffn_fwd -> eve_combine_fwd.  h [S,M]; vision_embed / text_embed [M] (`dtype`; may be
+ * NULL for EVE_MODE_NONE); wg [E,M] fp32; noise [S,E] as in eve_gate_top2_fwd; w1/b1/w2/b2 as in eve_ffn_fwd
+ * with E_local = E.  need_backward == 0: inference (z is not stored, the activation buffers live in the
+ * workspace, pass EVE_MOE_PASS_INFERENCE sizes it); != 0: EVE_MOE_PASS_FORWARD. */
+int eve_moe_fwd(const eve_moe_shape* shape, const void* h, const void* vision_embed, const void* text_embed,
+                const float* wg, const float* noise, int noise_is_uniform, const void* w1, const void* b1,
+                const void* w2, const void* b2, void* out, float* l_aux, void* saved, size_t saved_bytes,
+                int need_backward, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of eve_moe_fwd: eve_combine_bwd -> eve_ffn_bwd -> eve_gate_top2_bwd -> eve_route_bwd ->
+ * eve_gate_wgrad.  In: dout [S,M], d_l_aux [1] device scalar (NULL = the auxiliary loss was not used), the
+ * forward's inputs and its `saved` buffer.  Out (all overwritten): dh [S,M]; dwg [E,M] fp32 (NULL = not wanted);
+ * dvision / dtext [M] as shape->embed_dtype (NULL = not wanted; ignored for modes that do not use the
+ * embedding); dw1 / db1 / dw2 / db2 as eve_ffn_bwd.  workspace: EVE_MOE_PASS_BACKWARD. */
+int eve_moe_bwd(const eve_moe_shape* shape, const void* dout, const float* d_l_aux, const void* h,
+                const void* vision_embed, const void* text_embed, const float* wg, const void* w1, const void* w2,
+                const void* saved, size_t saved_bytes, void* dh, float* dwg, void* dvision, void* dtext, void* dw1,
+                void* db1, void* dw2, void* db2, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------- hard modality split of the non-MoE layers
  * Reference models/multiway_transformer.py:366-370: vision positions [:, :n_vis] go through

@@ -151,3 +151,34 @@ def test_gumbel_rsample_is_the_reference_draw():
     import numpy as np
     z = np.load(os.path.join(REPO, "tests", "golden", "noise_seed77.npz"))
     assert np.array_equal(a.numpy(), z["noise"])
+
+
+def test_fused_layer_buffer_layouts():
+    """eve_moe_saved_bytes / eve_moe_saved_offsets / eve_moe_workspace_bytes: host arithmetic, no GPU."""
+    lib = _lib.load()
+    S, T, M, I, E = 16 * 237, 237, 768, 3072, 32
+    C = int(lib.eve_capacity(S, E, 1.0, 4))
+    shape = _lib.MoEShape(S, T, 197, _lib.MODE_VL, M, I, E, C, _lib.ACT_QUICK_GELU, _lib.BF16, _lib.BF16)
+    ref = ctypes.addressof(shape)
+    n = len(_lib.MOE_SAVED_FIELDS)
+    sizes = {"gates": S * E * 4, "idx": S * 8, "loc": S * 8, "slot": S * 8, "weight": S * 8, "slot_token": E * C * 4,
+             "slot_weight": E * C * 4, "rows": E * 4, "exp_counts": E * 8, "xd": E * C * M * 2, "z": E * C * I * 2,
+             "a": E * C * I * 2, "y": E * C * M * 2}
+    for nb in (0, 1):
+        offs = (ctypes.c_size_t * n)()
+        assert lib.eve_moe_saved_offsets(ref, nb, ctypes.addressof(offs), n) == 0
+        total = lib.eve_moe_saved_bytes(ref, nb)
+        end = 0
+        for name, o in zip(_lib.MOE_SAVED_FIELDS, offs):
+            if not nb and name in ("xd", "z", "a", "y"):
+                assert o == ctypes.c_size_t(-1).value
+                continue
+            assert o % 256 == 0 and o >= end, name  # aligned, in order, no overlap
+            end = o + sizes[name]
+        assert end <= total < end + 256
+    inf, fwd, bwd = (lib.eve_moe_workspace_bytes(ref, p) for p in
+                     (_lib.MOE_PASS_INFERENCE, _lib.MOE_PASS_FORWARD, _lib.MOE_PASS_BACKWARD))
+    assert fwd >= S * E * 4 + lib.eve_gate_workspace_bytes(S, E)
+    assert inf >= fwd + E * C * (2 * M + I) * 2  # the activation buffers move into the workspace
+    assert bwd >= E * C * (2 * M + I) * 2 + S * E * 4 + lib.eve_ffn_bwd_workspace_bytes(E, E, C, M, I, _lib.BF16)
+    assert lib.eve_moe_saved_offsets(ref, 1, None, n) == -1 and lib.eve_moe_saved_bytes(None, 1) == 0
