@@ -6,7 +6,7 @@ import bench
 
 class A: pass
 dev = torch.device("cuda", 0)
-M, I, E, n_vis, T, B = 768, 3072, 32, 197, 237, 64
+M, I, E, n_vis, T, B = (1024, 4096, 32, 197, 237, 32) if "--large" in sys.argv else (768, 3072, 32, 197, 237, 64)
 moe = bench.build_layer(M, I, E, 1, 0, n_vis, torch.bfloat16, dev)
 g = torch.Generator().manual_seed(1234)
 h = torch.nn.functional.layer_norm(torch.randn(B, T, M, generator=g), (M,)).to(torch.bfloat16).to(dev)

@@ -68,6 +68,7 @@ alg = {  # kernel -> (algorithmic bytes, flops, note)
     "route_bwd_kernel": ((S + K) * M * b, 2.0 * S * M * E, "(K+S)*M*b"),
     "gate_wgrad_bf16_kernel": (S * M * b + 4 * S * E, 2.0 * S * M * E, "S*M*b + 4*S*E"),
     "gate_bwd32_kernel": (12 * E * S, 0, "gates, dlogits: ~12E B/token"),
+    "rows_colsum_kernel": (K * M * b, 0, "db2: dy rows in, K*M*b"),
 }
 print(f"workload: {line['config']['workload']}")
 print(f"S = {S} tokens, K = {K} kept assignments, bench line: {line['ms_per_step']} ms/step, {line['value']:.0f} tokens/s")
@@ -109,4 +110,5 @@ if tj and traffic:
     avg = sum(v["hbm_bytes"] for v in traffic.values()) / len(traffic)
     json.dump({"note": "per launch; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction); one launch "
                        "of each grouped-GEMM kernel per step, the weight-gradient launch computes both dW GEMMs",
+               "source_hash": line["config"].get("library_source_hash"),
                "kernels": traffic, "avg_hbm_bytes_per_launch": int(avg)}, open(tj, "w"), indent=1)
