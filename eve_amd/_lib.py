@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("EVE_MOE_LIB", LIB_PATH)  # A/B experiments: an altern
 F32, BF16 = 0, 1
 MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3
 ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 FFN_SHARED_GPU = 1
 
 _P, _I, _Z = c_void_p, c_int, c_size_t
@@ -36,7 +36,7 @@ SIGNATURES = {
     "eve_gate_top2_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "eve_gate_wgrad_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "eve_gate_wgrad": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "eve_dispatch_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "eve_dispatch_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "eve_dispatch_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "eve_embed_grad_workspace_bytes": (c_size_t, [_I, _I]),
     "eve_embed_grad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),

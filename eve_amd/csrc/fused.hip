@@ -155,7 +155,7 @@ extern "C" int eve_moe_fwd(const eve_moe_shape* p, const void* h, const void* vi
   if (int rc = eve_gate_logits_fwd(h, vision_embed, text_embed, wg, logits, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype, stream)) return rc;
   if (int rc = eve_gate_top2_fwd(logits, noise, noise_is_uniform, p->S, p->E, p->C, gates, idx, loc, slot, weight, slot_token, slot_weight,
                                  exp_counts, rows, l_aux, w + ws.off[WS_GATE], eve_gate_workspace_bytes(p->S, p->E), stream)) return rc;
-  if (int rc = eve_dispatch_fwd(h, vision_embed, text_embed, slot_token, xd, p->S, p->T, p->n_vis, p->mode, p->M, n, p->dtype, stream)) return rc;
+  if (int rc = eve_dispatch_fwd(h, vision_embed, text_embed, slot, slot_token, xd, p->S, p->T, p->n_vis, p->mode, p->M, n, p->dtype, stream)) return rc;
   if (int rc = eve_ffn_fwd(xd, w1, b1, w2, b2, z, a, y, rows, p->E, p->E, p->C, p->M, p->I, p->act, p->dtype, 0, stream)) return rc;
   return eve_combine_fwd(y, slot, weight, out, p->S, p->M, p->dtype, stream);
 }

@@ -213,6 +213,168 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------- row movers for M = 32 * NP * (16-byte chunks)
+// The model widths (768 = 3 passes, 1024 = 4, ... of 32 lanes x 16 bytes in bf16) get kernels whose trip counts are
+// compile-time: half a wave owns a row, a lane NP chunks of it, and all of a row's loads are issued before the
+// first use -- with two rows per wave and a grid of several waves per SIMD that keeps enough bytes in flight
+// for an HBM-bound mover.  Other widths take the generic kernels above.
+
+// dispatch, TOKEN-major: token s's row (+ embedding) is read ONCE and written to its (up to two) slots -- the
+// slot-major kernel above reads it once per slot, far apart in time (different experts), so from HBM twice.
+// Slots that hold no token are zero-filled afterwards, as combine_bwd does.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void dispatch_fwd_tok_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
+                                                               const T* __restrict__ temb, const int32_t* __restrict__ slot,
+                                                               const int32_t* __restrict__ slot_token, T* __restrict__ xd,
+                                                               int S, int T_, int n_vis, int mode, int num_slots) {
+  constexpr int N = Vec16<T>::N, M = 32 * NP * N;
+  const int lane = lane_id(), l32 = lane & 31, half = lane >> 5;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s0 = 2 * wave; s0 < S; s0 += 2 * nwaves) {
+    const int s = min(s0 + half, S - 1);
+    const bool live = s0 + half < S;
+    const int2 sl = *reinterpret_cast<const int2*>(slot + 2 * s);
+    const T* src = h + (size_t)s * M;
+    Vec16<T> v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) v[p] = load16<T>(src + (p * 32 + l32) * N);
+    if (mode != EVE_MODE_NONE) {
+      const T* emb = token_modality(s, T_, n_vis, mode) ? temb : vemb;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const Vec16<T> e = load16<T>(emb + (p * 32 + l32) * N);
+        float xs[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) xs[j] = v[p].get(j) + e.get(j);
+        v[p].set_all(xs);
+      }
+    }
+    if (live && sl.x >= 0) {
+      T* dst = xd + (size_t)sl.x * M;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) store16<T>(dst + (p * 32 + l32) * N, v[p]);
+    }
+    if (live && sl.y >= 0) {
+      T* dst = xd + (size_t)sl.y * M;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) store16<T>(dst + (p * 32 + l32) * N, v[p]);
+    }
+  }
+  for (int base = wave * 64; base < num_slots; base += nwaves * 64) {  // empty slots
+    const int sl = base + lane;
+    unsigned long long empty = __ballot(sl < num_slots && slot_token[min(sl, num_slots - 1)] < 0);
+    while (empty) {
+      const int k = __ffsll((long long)empty) - 1;
+      empty &= empty - 1;
+      T* dst = xd + (size_t)(base + k) * M;
+      for (int c = lane; c < M / N; c += 64) store16<T>(dst + c * N, zero16<T>());
+    }
+  }
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void combine_fwd_np_kernel(const T* __restrict__ y, const int32_t* __restrict__ slot,
+                                                             const float* __restrict__ weight, T* __restrict__ out, int S) {
+  constexpr int N = Vec16<T>::N, M = 32 * NP * N;
+  const int lane = lane_id(), l32 = lane & 31, half = lane >> 5;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s0 = 2 * wave; s0 < S; s0 += 2 * nwaves) {
+    const int s = min(s0 + half, S - 1);
+    const int2 sl = *reinterpret_cast<const int2*>(slot + 2 * s);
+    const float2 w = *reinterpret_cast<const float2*>(weight + 2 * s);
+    const T* y1 = y + (size_t)max(sl.x, 0) * M;
+    const T* y2 = y + (size_t)max(sl.y, 0) * M;
+    Vec16<T> v1[NP], v2[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {  // unconditional (row 0 when there is no slot): every load is in flight at once
+      v1[p] = load16<T>(y1 + (p * 32 + l32) * N);
+      v2[p] = load16<T>(y2 + (p * 32 + l32) * N);
+    }
+    if (s0 + half < S) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          acc[j] = sl.x >= 0 ? w.x * v1[p].get(j) : 0.f;
+          if (sl.y >= 0) acc[j] = fmaf(w.y, v2[p].get(j), acc[j]);
+        }
+        Vec16<T> o;
+        o.set_all(acc);
+        store16<T>(out + (size_t)s * M + (p * 32 + l32) * N, o);
+      }
+    }
+  }
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void combine_bwd_np_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                             const int32_t* __restrict__ slot,
+                                                             const int32_t* __restrict__ slot_token,
+                                                             const float* __restrict__ slot_weight, T* __restrict__ dy,
+                                                             float* __restrict__ d_weight, int S, int num_slots) {
+  constexpr int N = Vec16<T>::N, M = 32 * NP * N;
+  const int lane = lane_id(), l32 = lane & 31, half = lane >> 5;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s0 = 2 * wave; s0 < S; s0 += 2 * nwaves) {
+    const int s = min(s0 + half, S - 1);
+    const bool live = s0 + half < S;
+    const int2 sl = *reinterpret_cast<const int2*>(slot + 2 * s);
+    const int s1 = live ? sl.x : -1, s2 = live ? sl.y : -1;
+    const T* drow = dout + (size_t)s * M;
+    const T* y1 = y + (size_t)max(s1, 0) * M;
+    const T* y2 = y + (size_t)max(s2, 0) * M;
+    Vec16<T> d[NP], v1[NP], v2[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      d[p] = load16<T>(drow + (p * 32 + l32) * N);
+      v1[p] = load16<T>(y1 + (p * 32 + l32) * N);
+      v2[p] = load16<T>(y2 + (p * 32 + l32) * N);
+    }
+    const float w1 = s1 >= 0 ? slot_weight[s1] : 0.f, w2 = s2 >= 0 ? slot_weight[s2] : 0.f;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      Vec16<T> o1, o2;
+      float p1[N], p2[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float dj = d[p].get(j);
+        a1 = fmaf(dj, v1[p].get(j), a1);
+        a2 = fmaf(dj, v2[p].get(j), a2);
+        p1[j] = w1 * dj;
+        p2[j] = w2 * dj;
+      }
+      o1.set_all(p1);
+      o2.set_all(p2);
+      if (s1 >= 0) store16<T>(dy + (size_t)s1 * M + (p * 32 + l32) * N, o1);
+      if (s2 >= 0) store16<T>(dy + (size_t)s2 * M + (p * 32 + l32) * N, o2);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      a1 += __shfl_xor(a1, o, 64);
+      a2 += __shfl_xor(a2, o, 64);
+    }
+    if (l32 == 0 && live) {
+      d_weight[2 * s] = s1 >= 0 ? a1 : 0.f;
+      d_weight[2 * s + 1] = s2 >= 0 ? a2 : 0.f;
+    }
+  }
+  for (int base = wave * 64; base < num_slots; base += nwaves * 64) {  // empty slots
+    const int sl = base + lane;
+    unsigned long long empty = __ballot(sl < num_slots && slot_token[min(sl, num_slots - 1)] < 0);
+    while (empty) {
+      const int k = __ffsll((long long)empty) - 1;
+      empty &= empty - 1;
+      T* dst = dy + (size_t)(base + k) * M;
+      for (int c = lane; c < M / N; c += 64) store16<T>(dst + c * N, zero16<T>());
+    }
+  }
+}
+
 // ------------------------------------------------------------------ modality embed gradient
 // Column sums of dh by modality.  Stage 1: block = chunk of TS tokens, thread = one 16-byte column
 // chunk -> part[chunk][2][M]; stage 2: fixed-order sum over chunks (8 row groups x 32 columns per
@@ -439,6 +601,157 @@ __global__ __launch_bounds__(kRbThreads) void route_bwd_kernel(const T* __restri
   }
 }
 
+// ---- the same, bf16 activations, without block-wide phases: a WAVE owns 32 tokens x 64 columns ------------------
+// The block kernel above runs load -> barrier -> MFMA -> barrier -> add/store -> barrier -> column sums, three
+// dependent memory round trips per block and two rounds of blocks: it is bound by that latency chain, not by HBM.
+// Here a wave works alone on its item: its gathers (lanes consecutive ALONG the row: 8 lanes x 16 bytes = one
+// 128-byte line per token and slot, 8 lines per instruction) are in flight from the start, the 32 x 64 product goes
+// through a wave-private fp32 image in LDS into that row layout, and a wave that has a second item has its loads in
+// flight while the first one's column sums run.  The product is formed transposed (MFMA rows = columns of wg,
+// permuted so that a lane holds 16 consecutive columns of one token: 16-byte LDS writes), from wg fragments that
+// the block splits into bf16 hi / lo halves once.  Column sums by modality: token by token, as the block kernel.
+typedef __attribute__((ext_vector_type(8))) __bf16 rw_bf16x8;
+constexpr int kRwCols = 64;   // columns of a wave's item = 2 MFMA tiles
+constexpr int kRwLd = 68;     // floats per token row of a wave's image (+4: rows start in different banks)
+__global__ __launch_bounds__(256) void route_bwd_bf16_kernel(const bf16_t* __restrict__ dxd, const int32_t* __restrict__ slot,
+                                                             const float* __restrict__ dlogits, const float* __restrict__ wg,
+                                                             bf16_t* __restrict__ dh, float* __restrict__ part, int S, int T_,
+                                                             int n_vis, int mode, int M, int E, int ngroups) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ uint4 wfrag[8 * 64];  // fragment (tile q, k step ks, hi/lo) x lane
+  __shared__ __attribute__((aligned(16))) float image[4][32 * kRwLd];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.y * kRwCols;
+  const int t = lane & 31, hh = lane >> 5;  // MFMA view: token t, accumulator half hh
+  const int tq = lane >> 3, ch = lane & 7;  // row view: tokens 8 i + tq (i < 4), 16-byte chunk ch of the 64 columns
+  const int colr = min(c0 + 8 * ch, M - 8);
+  const bool col_ok = c0 + 8 * ch < M;
+  int grp = blockIdx.x * 4 + wave;
+  const int gstride = gridDim.x * 4;
+  int2 sl[4];
+  Vec16<bf16_t> v1[4], v2[4];
+  float4 dl4[4];
+  auto load_item = [&]() {  // the item's global loads, all in flight at once
+    const int s0 = grp * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = min(s0 + 8 * i + tq, S - 1);
+      sl[i] = *reinterpret_cast<const int2*>(slot + 2 * s);
+      v1[i] = load16<bf16_t>(dxd + (size_t)max(sl[i].x, 0) * M + colr);
+      v2[i] = load16<bf16_t>(dxd + (size_t)max(sl[i].y, 0) * M + colr);
+    }
+    // dlogits row of token t, experts 8 hh .. + 7 and 16 + 8 hh .. + 7 (the B operand: k = expert)
+    const float* dr = dlogits + (size_t)min(s0 + t, S - 1) * E;
+    if (E == 32) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dl4[k] = *reinterpret_cast<const float4*>(dr + (k >> 1) * 16 + 8 * hh + (k & 1) * 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = (k >> 1) * 16 + 8 * hh + (k & 1) * 4;
+        dl4[k] = make_float4(e < E ? dr[e] : 0.f, e + 1 < E ? dr[e + 1] : 0.f, e + 2 < E ? dr[e + 2] : 0.f,
+                             e + 3 < E ? dr[e + 3] : 0.f);
+      }
+    }
+  };
+  bool have = grp < ngroups;
+  if (have) load_item();
+  for (int p = threadIdx.x; p < 4 * 64; p += 256) {
+    const int l = p & 63, qk = p >> 6, q = qk >> 1, ks = qk & 1;
+    const int i = l & 31, kh = l >> 5;
+    // MFMA row i of tile q is accumulator register r = 4 (i >> 3) + (i & 3) of the lanes with hh = (i >> 2) & 1,
+    // and stands for column 32 q + 16 hh + r of the span
+    const int col = c0 + 32 * q + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
+    rw_bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = ks * 16 + 8 * kh + j;
+      const float v = (e < E && col < M) ? wg[(size_t)e * M + col] : 0.f;
+      const __bf16 hb = static_cast<__bf16>(v);
+      hi[j] = hb;
+      lo[j] = static_cast<__bf16>(v - static_cast<float>(hb));
+    }
+    wfrag[(qk * 2 + 0) * 64 + l] = __builtin_bit_cast(uint4, hi);
+    wfrag[(qk * 2 + 1) * 64 + l] = __builtin_bit_cast(uint4, lo);
+  }
+  __syncthreads();
+  float* img = image[wave];
+  while (have) {
+    const int grp_c = grp, s0 = grp * 32;
+    rw_bf16x8 dhi[2], dlo[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 f = dl4[ks * 2 + (j >> 2)];
+        const float v = (j & 3) == 0 ? f.x : (j & 3) == 1 ? f.y : (j & 3) == 2 ? f.z : f.w;
+        const __bf16 hb = static_cast<__bf16>(v);
+        dhi[ks][j] = hb;
+        dlo[ks][j] = static_cast<__bf16>(v - static_cast<float>(hb));
+      }
+    const unsigned tm = (unsigned)__ballot(lane < 32 && s0 + t < S && token_modality(min(s0 + t, S - 1), T_, n_vis, mode) != 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const rw_bf16x8 wh = __builtin_bit_cast(rw_bf16x8, wfrag[((q * 2 + ks) * 2 + 0) * 64 + lane]);
+        const rw_bf16x8 wl = __builtin_bit_cast(rw_bf16x8, wfrag[((q * 2 + ks) * 2 + 1) * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, dlo[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, dhi[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, dhi[ks], acc, 0, 0, 0);
+      }
+      float* g = img + t * kRwLd + 32 * q + 16 * hh;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<float4*>(g + 4 * k) = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tok = 8 * i + tq, s = s0 + tok;
+      float* g = img + tok * kRwLd + 8 * ch;
+      const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
+      const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      float ov[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ov[j] = (gv[j] + (sl[i].x >= 0 ? v1[i].get(j) : 0.f)) + (sl[i].y >= 0 ? v2[i].get(j) : 0.f);
+      Vec16<bf16_t> o;
+      o.set_all(ov);
+      const bool live = s < S;
+      if (live && col_ok) store16<bf16_t>(dh + (size_t)s * M + colr, o);
+      if (part) {  // the rounded values (zero for rows past the end) back into the image for the column sums
+        *reinterpret_cast<float4*>(g) = live ? make_float4(o.get(0), o.get(1), o.get(2), o.get(3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(g + 4) = live ? make_float4(o.get(4), o.get(5), o.get(6), o.get(7)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // the next item's loads go out before this one's column sums
+    grp += gstride;
+    have = grp < ngroups;
+    if (have) load_item();
+    if (part) {  // lane = column: sums over the item's tokens by modality, token by token
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      float av = 0.f, at = 0.f;
+#pragma unroll 8
+      for (int tt = 0; tt < 32; ++tt) {
+        const float x = img[tt * kRwLd + lane];
+        if ((tm >> tt) & 1u) at += x; else av += x;
+      }
+      if (c0 + lane < M) {
+        part[((size_t)grp_c * 2 + 0) * M + c0 + lane] = av;
+        part[((size_t)grp_c * 2 + 1) * M + c0 + lane] = at;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is rewritten by the next item
+    __builtin_amdgcn_wave_barrier();
+  }
+#endif
+}
+
 // fixed-order sum of the per-block partials: block = 32 columns x 32 slices of the partial rows
 template <typename TO>
 __global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* __restrict__ part, TO* __restrict__ dv,
@@ -472,9 +785,33 @@ static int check_rows(const char* who, int M, int dtype) {
   return EVE_OK;
 }
 
+// passes of 32 lanes x 16 bytes that make up a row when the width has a compile-time kernel, else 0
+static int row_passes(int M, int dtype) {
+  const int per_pass = 32 * (dtype == EVE_BF16 ? 8 : 4);
+  if (M % per_pass) return 0;
+  const int np = M / per_pass;
+  return (np >= 1 && np <= 4) || np == 6 || np == 8 ? np : 0;
+}
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+// two rows per wave, four waves per block, every wave resident at once up to 8 blocks per CU of a 256-CU part
+static inline int pair_grid(int rows) { return max(1, min(ceil_div(rows, 8), 4096)); }
+
 }  // namespace eve
 
 using namespace eve;
+
+// KERNEL<TT, NP> for the runtime pass count np
+#define EVE_LAUNCH_NP(KERNEL, TT, np, grid, st, ...)                                              \
+  do {                                                                                            \
+    switch (np) {                                                                                 \
+      case 1: hipLaunchKernelGGL((KERNEL<TT, 1>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+      case 2: hipLaunchKernelGGL((KERNEL<TT, 2>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+      case 3: hipLaunchKernelGGL((KERNEL<TT, 3>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+      case 4: hipLaunchKernelGGL((KERNEL<TT, 4>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+      case 6: hipLaunchKernelGGL((KERNEL<TT, 6>), grid, dim3(256), 0, st, __VA_ARGS__); break;    \
+      default: hipLaunchKernelGGL((KERNEL<TT, 8>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+    }                                                                                             \
+  } while (0)
 
 #define EVE_DISPATCH_DTYPE(dtype, KERNEL, grid, block, st, ...)                                     \
   do {                                                                                              \
@@ -482,7 +819,7 @@ using namespace eve;
     else hipLaunchKernelGGL((KERNEL<bf16_t>), grid, block, 0, st, __VA_ARGS__);                     \
   } while (0)
 
-extern "C" int eve_dispatch_fwd(const void* h, const void* vision_embed, const void* text_embed,
+extern "C" int eve_dispatch_fwd(const void* h, const void* vision_embed, const void* text_embed, const int32_t* slot,
                                 const int32_t* slot_token, void* xd, int S, int T, int n_vis, int mode, int M,
                                 int num_slots, int dtype, void* stream) {
   EVE_REQUIRE(h && slot_token && xd, EVE_ERR_ARG, "eve_dispatch_fwd: null pointer");
@@ -491,6 +828,19 @@ extern "C" int eve_dispatch_fwd(const void* h, const void* vision_embed, const v
   if (mode != EVE_MODE_NONE)
     EVE_REQUIRE(vision_embed && text_embed && T > 0 && S % T == 0, EVE_ERR_ARG, "eve_dispatch_fwd: embeddings / T required for mode %d", mode);
   hipStream_t st = S_(stream);
+  const int np = row_passes(M, dtype);
+  if (slot && np && aligned_to(slot, 8) && aligned_to(h, 16) && aligned_to(xd, 16) &&
+      (mode == EVE_MODE_NONE || (aligned_to(vision_embed, 16) && aligned_to(text_embed, 16)))) {
+    // token-major: each token row is read once for both of its slots
+    if (dtype == EVE_F32)
+      EVE_LAUNCH_NP(dispatch_fwd_tok_kernel, float, np, dim3(pair_grid(S)), st, (const float*)h, (const float*)vision_embed,
+                    (const float*)text_embed, slot, slot_token, (float*)xd, S, T, n_vis, mode, num_slots);
+    else
+      EVE_LAUNCH_NP(dispatch_fwd_tok_kernel, bf16_t, np, dim3(pair_grid(S)), st, (const bf16_t*)h, (const bf16_t*)vision_embed,
+                    (const bf16_t*)text_embed, slot, slot_token, (bf16_t*)xd, S, T, n_vis, mode, num_slots);
+    EVE_CHECK_LAUNCH("dispatch_fwd_tok_kernel");
+    return EVE_OK;
+  }
   if (dtype == EVE_F32)
     hipLaunchKernelGGL((dispatch_fwd_kernel<float>), dim3(row_grid(num_slots)), dim3(256), 0, st, (const float*)h,
                        (const float*)vision_embed, (const float*)text_embed, slot_token, (float*)xd, T, n_vis, mode, M,
@@ -528,6 +878,15 @@ extern "C" int eve_combine_fwd(const void* y, const int32_t* slot, const float* 
   EVE_REQUIRE(S > 0, EVE_ERR_ARG, "eve_combine_fwd: bad shape");
   if (int rc = check_rows("eve_combine_fwd", M, dtype)) return rc;
   hipStream_t st = S_(stream);
+  const int np = row_passes(M, dtype);
+  if (np && aligned_to(slot, 8) && aligned_to(weight, 8) && aligned_to(y, 16) && aligned_to(out, 16)) {
+    if (dtype == EVE_F32)
+      EVE_LAUNCH_NP(combine_fwd_np_kernel, float, np, dim3(pair_grid(S)), st, (const float*)y, slot, weight, (float*)out, S);
+    else
+      EVE_LAUNCH_NP(combine_fwd_np_kernel, bf16_t, np, dim3(pair_grid(S)), st, (const bf16_t*)y, slot, weight, (bf16_t*)out, S);
+    EVE_CHECK_LAUNCH("combine_fwd_np_kernel");
+    return EVE_OK;
+  }
   if (dtype == EVE_F32)
     hipLaunchKernelGGL((combine_fwd_kernel<float>), dim3(row_grid(S)), dim3(256), 0, st, (const float*)y, slot, weight,
                        (float*)out, S, M);
@@ -545,6 +904,17 @@ extern "C" int eve_combine_bwd(const void* dout, const void* y, const int32_t* s
   EVE_REQUIRE(S > 0 && num_slots > 0, EVE_ERR_ARG, "eve_combine_bwd: bad shape");
   if (int rc = check_rows("eve_combine_bwd", M, dtype)) return rc;
   hipStream_t st = S_(stream);
+  const int np = row_passes(M, dtype);
+  if (np && aligned_to(slot, 8) && aligned_to(dout, 16) && aligned_to(y, 16) && aligned_to(dy, 16)) {
+    if (dtype == EVE_F32)
+      EVE_LAUNCH_NP(combine_bwd_np_kernel, float, np, dim3(pair_grid(S)), st, (const float*)dout, (const float*)y, slot,
+                    slot_token, slot_weight, (float*)dy, d_weight, S, num_slots);
+    else
+      EVE_LAUNCH_NP(combine_bwd_np_kernel, bf16_t, np, dim3(pair_grid(S)), st, (const bf16_t*)dout, (const bf16_t*)y, slot,
+                    slot_token, slot_weight, (bf16_t*)dy, d_weight, S, num_slots);
+    EVE_CHECK_LAUNCH("combine_bwd_np_kernel");
+    return EVE_OK;
+  }
   const int grid = max(1, min(ceil_div(S, 8), 8192));
   if (dtype == EVE_F32)
     hipLaunchKernelGGL((combine_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)y, slot,
@@ -628,6 +998,25 @@ extern "C" int eve_route_bwd(const void* dxd, const int32_t* slot, const float* 
   static_assert(kRbTok == kEmbedTS, "eve_embed_grad_workspace_bytes sizes the partials of both paths");
   hipStream_t st = S_(stream);
   const int nblk = ceil_div(S, kRbTok);
+  if (dtype == EVE_BF16 && aligned_to(slot, 8) && aligned_to(dxd, 16) && aligned_to(dh, 16)) {
+    float* part = want_embed ? static_cast<float*>(workspace) : nullptr;
+    // one round of blocks: 4 waves per block, 3 blocks per CU (LDS), 256 CUs; a wave walks its items
+    const int spans = ceil_div(M, kRwCols);
+    const int bx = max(1, min(ceil_div(nblk, 4), max(1, 768 / spans)));
+    hipLaunchKernelGGL(route_bwd_bf16_kernel, dim3(bx, spans), dim3(256), 0, st, (const bf16_t*)dxd, slot, dlogits, wg,
+                       (bf16_t*)dh, part, S, T, n_vis, mode, M, E, nblk);
+    EVE_CHECK_LAUNCH("route_bwd_bf16_kernel");
+    if (want_embed) {
+      if (embed_dtype == EVE_F32)
+        hipLaunchKernelGGL(embed_grad_final32_kernel<float>, dim3(ceil_div(2 * M, 32)), dim3(1024), 0, st, part,
+                           (float*)dvision, (float*)dtext, M, nblk);
+      else
+        hipLaunchKernelGGL(embed_grad_final32_kernel<bf16_t>, dim3(ceil_div(2 * M, 32)), dim3(1024), 0, st, part,
+                           (bf16_t*)dvision, (bf16_t*)dtext, M, nblk);
+      EVE_CHECK_LAUNCH("embed_grad_final32_kernel");
+    }
+    return EVE_OK;
+  }
   const size_t lds = route_bwd_lds(M);
   const int Mb = route_bwd_slab(M);
   float* part = want_embed ? static_cast<float*>(workspace) : nullptr;

@@ -171,12 +171,15 @@ def gate_wgrad(h2d, vemb, temb, dlogits, T: int, n_vis: int, mode: int) -> torch
     return dwg
 
 
-def dispatch_fwd(h2d, vemb, temb, slot_token: torch.Tensor, T: int, n_vis: int, mode: int) -> torch.Tensor:
-    _chk(h2d, "hidden"), _chk(slot_token, "slot_token", torch.int32)
+def dispatch_fwd(h2d, vemb, temb, slot_token: torch.Tensor, T: int, n_vis: int, mode: int,
+                 slot: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`slot` [S,2] (the gate's forward map): each token row is then read once for both of its slots."""
+    _chk(h2d, "hidden"), _chk(slot_token, "slot_token", torch.int32), _chk(slot, "slot", torch.int32)
     S, M = h2d.shape
     n = slot_token.numel()
+    assert slot is None or tuple(slot.shape) == (S, 2)
     xd = torch.empty(n, M, dtype=h2d.dtype, device=h2d.device)
-    PROFILE.call("eve_dispatch_fwd", _p(h2d), _p(vemb), _p(temb), _p(slot_token), _p(xd), S, T, n_vis, mode, M, n,
+    PROFILE.call("eve_dispatch_fwd", _p(h2d), _p(vemb), _p(temb), _p(slot), _p(slot_token), _p(xd), S, T, n_vis, mode, M, n,
               _dt(h2d), _stream())
     return xd
 

@@ -334,7 +334,7 @@ class _RouteDispatchFn(torch.autograd.Function):
         logits = ops.gate_logits(h2d, ve, te, wg32, T, n_vis, mode)
         C = ops.capacity(S, E, cap_factor, min_capacity)
         r = ops.gate_top2(logits, noise.contiguous(), C, noise_is_uniform)
-        xd = ops.dispatch_fwd(h2d, ve, te, r.slot_token, T, n_vis, mode)
+        xd = ops.dispatch_fwd(h2d, ve, te, r.slot_token, T, n_vis, mode, slot=r.slot)
         ctx.dims, ctx.sec = (B, T, M, n_vis, mode), (r.S, r.E, r.C)
         ctx.set_materialize_grads(False)  # no zero tensors for the index outputs' "gradients"
         # (not the Routing object: it holds r.weight, an output of this Function -- a reference cycle through ctx)

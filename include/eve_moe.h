@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 6
+#define EVE_MOE_ABI_VERSION 7
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -145,9 +145,12 @@ int eve_gate_wgrad(const void* h, const void* vision_embed, const void* text_emb
 
 /* xd[slot,:] = round_dtype(h[tok,:] + embed(tok)) for tok = slot_token[slot] >= 0, else 0.
  * Replaces the modality add plus einsum("sec,sm->ecm", dispatch_mask, reshaped_input),
- * models/sharded_moe.py:350-367.  Writes all E*C rows. */
-int eve_dispatch_fwd(const void* h, const void* vision_embed, const void* text_embed, const int32_t* slot_token,
-                     void* xd, int S, int T, int n_vis, int mode, int M, int num_slots, int dtype, void* stream);
+ * models/sharded_moe.py:350-367.  Writes all E*C rows.  `slot` [S,2] is the forward map of eve_gate_top2_fwd
+ * (the inverse of slot_token); with it each token row is read once for both of its slots.  It may be NULL:
+ * the rows are then gathered slot by slot from slot_token alone (same result, a token's row read twice). */
+int eve_dispatch_fwd(const void* h, const void* vision_embed, const void* text_embed, const int32_t* slot,
+                     const int32_t* slot_token, void* xd, int S, int T, int n_vis, int mode, int M, int num_slots,
+                     int dtype, void* stream);
 
 /* dh[s,:] = dxd[slot[s,0],:] + dxd[slot[s,1],:] + sum_e dlogits[s,e] * wg[e,:]  (slots < 0 skipped;
  * dlogits may be NULL).  Backward of :350-367 plus the input gradient of the gate's Linear (:292). */

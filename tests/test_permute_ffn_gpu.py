@@ -36,6 +36,9 @@ def test_dispatch_and_combine_roundtrip(dtype, B, T, n_vis, M, E, mode):
     ref = torch.zeros(E * C, M, dtype=dtype)
     ref[st >= 0] = x[st[st >= 0]]
     assert torch.equal(xd, ref), "dispatch must be an exact row gather"
+    # with the forward map the rows move token-major (each token row read once for both slots): same result
+    xd2 = ops.dispatch_fwd(h.reshape(S, M).to(DEV), ve, te, r.slot_token, T, n_vis, ops.MODES[mode], slot=r.slot).cpu()
+    assert torch.equal(xd2, ref), "token-major dispatch must be the same exact row gather"
 
     # combine forward / backward against dense arithmetic in fp64
     y = torch.randn(E * C, M, generator=g).to(dtype)
