@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("EVE_MOE_LIB", LIB_PATH)  # A/B experiments: an altern
 F32, BF16 = 0, 1
 MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3
 ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 FFN_SHARED_GPU = 1
 
 _P, _I, _Z = c_void_p, c_int, c_size_t
@@ -50,6 +50,9 @@ SIGNATURES = {
     "eve_ffn_fwd": (c_int, [_P] * 9 + [_I] * 8 + [_P]),
     "eve_ffn_bwd": (c_int, [_P] * 13 + [_I] * 8 + [_P, _Z, _P]),
     "eve_ffn_bwd_workspace_bytes": (c_size_t, [_I] * 6),
+    "eve_scale_residual_fwd": (c_int, [_P] * 5 + [_I] * 4 + [_P]),
+    "eve_scale_residual_workspace_bytes": (c_size_t, [_I, _I]),
+    "eve_scale_residual_bwd": (c_int, [_P] * 6 + [_I] * 4 + [_P, _Z, _P]),
     "eve_moe_saved_bytes": (c_size_t, [_P, _I]),
     "eve_moe_workspace_bytes": (c_size_t, [_P, _I]),
     "eve_moe_saved_offsets": (c_int, [_P, _I, _P, _I]),

@@ -199,6 +199,122 @@ __global__ __launch_bounds__(256) void split_permute_kernel(const T* __restrict_
   }
 }
 
+// ------------------------------------------------------------ layer-scale residual branch
+// out = residual + (x * gamma) * row_scale: `residual + self.drop_path(hidden_states * self.gamma_k)` of the encoder
+// layer (reference models/multiway_transformer.py:341 / :408) in one pass instead of a multiply, the DropPath
+// multiply and an add.  Each product and the sum are rounded to fp32 separately (no contraction), so the fp32 result
+// is the reference's op chain bit for bit; bf16 rounds once at the end.  row_scale [B] = mask / keep_prob of DropPath
+// (NULL = no DropPath), gamma NULL = no layer scale.  Thread per 16-byte chunk, grid-stride: a plain stream.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                                 const T* __restrict__ row_scale, const T* __restrict__ residual,
+                                                                 T* __restrict__ out, long nchunks, int chunks_per_row, int T_) {
+  constexpr int N = Vec16<T>::N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / chunks_per_row;
+    const int c = (int)(i - row * chunks_per_row);
+    const Vec16<T> xv = load16<T>(x + i * N), rv = load16<T>(residual + i * N);
+    float v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = xv.get(j);
+    if (gamma) {
+      const Vec16<T> g = load16<T>(gamma + c * N);
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = v[j] * g.get(j);
+    }
+    if (row_scale) {
+      const float rs = to_f32<T>(row_scale[row / T_]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = v[j] * rs;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = rv.get(j) + v[j];
+    Vec16<T> o;
+    o.set_all(v);
+    store16<T>(out + i * N, o);
+  }
+}
+
+// Backward: dx = (dout * row_scale) * gamma and the per-block partial column sums of (dout * row_scale) * x (the
+// gradient of gamma).  Block = kSrTok rows; thread (rsub, c) walks rows rsub, rsub + nsub, ... of the block for
+// column chunk c; the row sub-groups are combined through LDS in a fixed order.
+constexpr int kSrTok = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x,
+                                                                 const T* __restrict__ gamma, const T* __restrict__ row_scale,
+                                                                 T* __restrict__ dx, float* __restrict__ part, int S, int T_, int M) {
+  constexpr int N = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [nsub][M]
+  const int chunks = M / N;
+  const int nsub = max(1, (int)blockDim.x / chunks);
+  const int r0 = blockIdx.x * kSrTok, r1 = min(S, r0 + kSrTok);
+  for (int c0 = 0; c0 < chunks; c0 += blockDim.x) {  // one trip unless a row has more chunks than the block threads
+    const int rsub = chunks >= (int)blockDim.x ? 0 : threadIdx.x / chunks;
+    const int c = chunks >= (int)blockDim.x ? c0 + threadIdx.x : threadIdx.x % chunks;
+    const bool on = c < chunks && rsub < nsub;
+    float acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.f;
+    if (on) {
+      Vec16<T> g;
+      if (gamma) g = load16<T>(gamma + c * N);
+      constexpr int U = 4;  // rows whose loads are issued together
+      for (int rb = r0 + rsub; rb < r1; rb += U * nsub) {
+        Vec16<T> dv[U], xv[U];
+        float rs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = min(rb + u * nsub, r1 - 1);  // clamped: rows past the end are loaded again and not stored
+          const size_t o = (size_t)r * M + (size_t)c * N;
+          dv[u] = load16<T>(dout + o);
+          if (gamma) xv[u] = load16<T>(x + o);
+          rs[u] = row_scale ? to_f32<T>(row_scale[r / T_]) : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = rb + u * nsub;
+          if (r >= r1) break;
+          const size_t o = (size_t)r * M + (size_t)c * N;
+          float d[N];
+#pragma unroll
+          for (int j = 0; j < N; ++j) d[j] = dv[u].get(j);
+          if (row_scale) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) d[j] = d[j] * rs[u];
+          }
+          Vec16<T> ov;
+          if (gamma) {
+            float dxv[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              acc[j] += d[j] * xv[u].get(j);
+              dxv[j] = d[j] * g.get(j);
+            }
+            ov.set_all(dxv);
+          } else {
+            ov.set_all(d);
+          }
+          store16<T>(dx + o, ov);
+        }
+      }
+    }
+    if (!part) continue;  // block-uniform
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) red[rsub * M + c * N + j] = acc[j];
+    }
+    __syncthreads();
+    const int cols_here = min(chunks - c0, (int)blockDim.x) * N;
+    for (int i = threadIdx.x; i < cols_here; i += blockDim.x) {
+      float sum = red[c0 * N + i];
+      for (int k = 1; k < nsub; ++k) sum += red[k * M + c0 * N + i];
+      part[(size_t)blockIdx.x * M + c0 * N + i] = sum;
+    }
+    __syncthreads();
+  }
+}
+
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static int check_split(const char* who, int B, int T, int n_vis, int R, int M, int dtype, bool rows_in_regs) {
@@ -279,5 +395,67 @@ extern "C" int eve_split_permute(const void* src, void* dst, int B, int T, int n
     hipLaunchKernelGGL((split_permute_kernel<bf16_t>), dim3(grid), dim3(256), 0, S_(stream), (const bf16_t*)src,
                        (bf16_t*)dst, S, T, n_vis, R, M, to_groups);
   EVE_CHECK_LAUNCH("split_permute_kernel");
+  return EVE_OK;
+}
+
+extern "C" size_t eve_scale_residual_workspace_bytes(int S, int M) {
+  if (S <= 0 || M <= 0) return 0;
+  return (size_t)ceil_div(S, kSrTok) * M * sizeof(float);
+}
+
+static int check_scale_residual(const char* who, int S, int T, int M, int dtype, bool has_row_scale) {
+  if (dtype != EVE_F32 && dtype != EVE_BF16) { set_error("%s: bad dtype %d", who, dtype); return EVE_ERR_ARG; }
+  const int n = dtype == EVE_BF16 ? 8 : 4;
+  if (S <= 0 || M <= 0 || M % n != 0) { set_error("%s: bad shape S=%d M=%d (M %% %d)", who, S, M, n); return EVE_ERR_ARG; }
+  if (has_row_scale && (T <= 0 || S % T != 0)) { set_error("%s: S=%d not a multiple of T=%d", who, S, T); return EVE_ERR_ARG; }
+  return EVE_OK;
+}
+
+extern "C" int eve_scale_residual_fwd(const void* x, const void* gamma, const void* row_scale, const void* residual,
+                                      void* out, int S, int T, int M, int dtype, void* stream) {
+  EVE_REQUIRE(x && residual && out, EVE_ERR_ARG, "eve_scale_residual_fwd: null pointer");
+  if (int rc = check_scale_residual("eve_scale_residual_fwd", S, T, M, dtype, row_scale != nullptr)) return rc;
+  const int n = dtype == EVE_BF16 ? 8 : 4;
+  const long nchunks = (long)S * (M / n);
+  const int grid = (int)max(1L, min((nchunks + 255) / 256, 8192L));
+  if (dtype == EVE_F32)
+    hipLaunchKernelGGL(scale_residual_fwd_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), (const float*)x, (const float*)gamma,
+                       (const float*)row_scale, (const float*)residual, (float*)out, nchunks, M / n, max(T, 1));
+  else
+    hipLaunchKernelGGL(scale_residual_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, S_(stream), (const bf16_t*)x,
+                       (const bf16_t*)gamma, (const bf16_t*)row_scale, (const bf16_t*)residual, (bf16_t*)out, nchunks, M / n,
+                       max(T, 1));
+  EVE_CHECK_LAUNCH("scale_residual_fwd_kernel");
+  return EVE_OK;
+}
+
+extern "C" int eve_scale_residual_bwd(const void* dout, const void* x, const void* gamma, const void* row_scale, void* dx,
+                                      float* dgamma, int S, int T, int M, int dtype, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  EVE_REQUIRE(dout && dx, EVE_ERR_ARG, "eve_scale_residual_bwd: null pointer");
+  EVE_REQUIRE(!gamma || (x && dgamma), EVE_ERR_ARG, "eve_scale_residual_bwd: x and dgamma are required with gamma");
+  if (int rc = check_scale_residual("eve_scale_residual_bwd", S, T, M, dtype, row_scale != nullptr)) return rc;
+  const size_t need = gamma ? eve_scale_residual_workspace_bytes(S, M) : 0;
+  EVE_REQUIRE(!need || (workspace && workspace_bytes >= need), EVE_ERR_WORKSPACE, "eve_scale_residual_bwd: workspace %zu < %zu",
+              workspace_bytes, need);
+  const int n = dtype == EVE_BF16 ? 8 : 4;
+  const int chunks = M / n;
+  const int nsub = chunks >= 256 ? 1 : 256 / chunks;
+  const size_t lds = (size_t)nsub * M * sizeof(float);
+  EVE_REQUIRE(lds <= 64 * 1024, EVE_ERR_UNSUPPORTED, "eve_scale_residual_bwd: M=%d too wide", M);
+  const int nblk = ceil_div(S, kSrTok);
+  float* part = gamma ? static_cast<float*>(workspace) : nullptr;
+  hipStream_t st = S_(stream);
+  if (dtype == EVE_F32)
+    hipLaunchKernelGGL(scale_residual_bwd_kernel<float>, dim3(nblk), dim3(256), lds, st, (const float*)dout, (const float*)x,
+                       (const float*)gamma, (const float*)row_scale, (float*)dx, part, S, max(T, 1), M);
+  else
+    hipLaunchKernelGGL(scale_residual_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, (const bf16_t*)dout, (const bf16_t*)x,
+                       (const bf16_t*)gamma, (const bf16_t*)row_scale, (bf16_t*)dx, part, S, max(T, 1), M);
+  EVE_CHECK_LAUNCH("scale_residual_bwd_kernel");
+  if (gamma) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(M, 32)), dim3(1024), 0, st, part, dgamma, M, nblk);
+    EVE_CHECK_LAUNCH("colsum_final_kernel");
+  }
   return EVE_OK;
 }

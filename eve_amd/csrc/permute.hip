@@ -1023,11 +1023,9 @@ extern "C" int eve_route_bwd(const void* dxd, const int32_t* slot, const float* 
 #define EVE_RB_LAUNCH(TT)                                                                                          \
   do {                                                                                                             \
     auto kern = route_bwd_kernel<TT>;                                                                              \
-    static size_t attr_bytes = 0;                                                                                  \
-    if (lds > 64 * 1024 && lds > attr_bytes) {                                                                     \
+    if (lds > 64 * 1024) { /* a per-device attribute: set on every launch (cheap next to the kernel) */            \
       EVE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds) == hipSuccess, EVE_ERR_LAUNCH, "eve_route_bwd: cannot reserve %zu bytes of LDS", lds); \
-      attr_bytes = lds;                                                                                            \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, dim3(nblk, ceil_div(M, Mb)), dim3(kRbThreads), lds, st, (const TT*)dxd, slot, dlogits,  \
                        wg, (TT*)dh, part, S, T, n_vis, mode, M, E, Mb);                                            \

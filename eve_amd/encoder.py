@@ -48,6 +48,35 @@ class DropPath(nn.Module):
         return x * mask
 
 
+class _ScaleResidualFn(torch.autograd.Function):
+    """residual + drop_path(x * gamma) in one pass (eve_scale_residual_fwd/bwd; reference
+    multiway_transformer.py:341, :408).  `row_scale` [B] is DropPath's per-sample mask / keep_prob, or None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, row_scale, residual):  # type: ignore[override]
+        from . import ops
+        B, T, M = x.shape
+        x2 = x.contiguous().view(B * T, M)
+        g = None if gamma is None else gamma.to(x.dtype).contiguous()
+        rs = None if row_scale is None else row_scale.to(x.dtype).contiguous()
+        out = ops.scale_residual_fwd(x2, g, rs, residual.contiguous().view(B * T, M), T)
+        ctx.save_for_backward(x2 if g is not None else None, g, rs)
+        ctx.dims = (B, T, M)
+        ctx.gamma_dtype = None if gamma is None else gamma.dtype
+        return out.view(B, T, M)
+
+    @staticmethod
+    def backward(ctx, dout):  # type: ignore[override]
+        from . import ops
+        x2, g, rs = ctx.saved_tensors
+        B, T, M = ctx.dims
+        dout = dout.contiguous()
+        dx, dgamma = ops.scale_residual_bwd(dout.view(B * T, M), x2, g, rs, T)
+        if dgamma is not None and dgamma.dtype != ctx.gamma_dtype:
+            dgamma = dgamma.to(ctx.gamma_dtype)
+        return dx.view(B, T, M), dgamma, None, dout
+
+
 class Attention(nn.Module):
     """Reference :57-132.  `qkv` has no bias of its own; `q_bias` / `v_bias` are separate parameters (the key
     bias is fixed at zero), as in BEiT."""
@@ -169,14 +198,28 @@ class MultiwayTransformerEnocderLayer(nn.Module):
             return self._moe(self.norm2_imag(h))  # the reference passes no mode here (:362)
         return self._split(h, mode=mode)
 
+    def _branch(self, residual: Tensor, x: Tensor, gamma) -> Tensor:
+        """`residual + self.drop_path(x * gamma)` (reference :341, :408): on the GPU one fused pass."""
+        if not (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and x.dtype == residual.dtype
+                and x.shape == residual.shape and x.shape[-1] % 8 == 0):
+            return residual + self.drop_path(x * gamma)
+        row_scale = None
+        p = getattr(self.drop_path, "drop_prob", 0.0)
+        if p > 0.0 and self.training:  # DropPath's own draw (same generator consumption), applied inside the kernel
+            keep = 1.0 - p
+            row_scale = x.new_empty(x.shape[0]).bernoulli_(keep)
+            if keep > 0.0:
+                row_scale.div_(keep)
+        return _ScaleResidualFn.apply(x, gamma if isinstance(gamma, Tensor) else None, row_scale, residual)
+
     def forward(self, hidden_states: Tensor, attention_mask=None, relative_position_bias=None, mode='vl') -> Tensor:
         residual = hidden_states
         hidden_states = self.attn(self.norm1(hidden_states), mask=attention_mask,
                                   relative_position_bias=relative_position_bias)
-        hidden_states = residual + self.drop_path(hidden_states * self.gamma_1)
+        hidden_states = self._branch(residual, hidden_states, self.gamma_1)
         residual = hidden_states
         hidden_states = self._ffn(hidden_states, mode)
-        return residual + self.drop_path(hidden_states * self.gamma_2)
+        return self._branch(residual, hidden_states, self.gamma_2)
 
 
 MultiwayTransformerEncoderLayer = MultiwayTransformerEnocderLayer

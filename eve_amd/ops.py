@@ -325,3 +325,26 @@ def split_permute(src, B: int, T: int, n_vis: int, R: int, to_groups: bool):
     dst = torch.empty((2, R, M) if to_groups else (B, T, M), dtype=src.dtype, device=src.device)
     PROFILE.call("eve_split_permute", _p(src), _p(dst), B, T, n_vis, R, M, 1 if to_groups else 0, _dt(src), _stream())
     return dst
+
+
+# ----------------------------------------------------- layer-scale residual branch of the encoder layer
+def scale_residual_fwd(x, gamma, row_scale, residual, T: int):
+    """residual + (x * gamma) * row_scale[s // T]; x, residual [S,M]; gamma [M] | None; row_scale [S // T] | None."""
+    _chk(x, "x"), _chk(residual, "residual", x.dtype), _chk(gamma, "gamma", x.dtype), _chk(row_scale, "row_scale", x.dtype)
+    S, M = x.shape
+    out = torch.empty_like(x)
+    PROFILE.call("eve_scale_residual_fwd", _p(x), _p(gamma), _p(row_scale), _p(residual), _p(out), S, T, M, _dt(x), _stream())
+    return out
+
+
+def scale_residual_bwd(dout, x, gamma, row_scale, T: int):
+    """-> (dx [S,M], dgamma [M] fp32 | None)."""
+    _chk(dout, "dout"), _chk(x, "x", dout.dtype), _chk(gamma, "gamma", dout.dtype), _chk(row_scale, "row_scale", dout.dtype)
+    S, M = dout.shape
+    dx = torch.empty_like(dout)
+    dgamma = torch.empty(M, dtype=torch.float32, device=dout.device) if gamma is not None else None
+    nbytes = _lib.load().eve_scale_residual_workspace_bytes(S, M) if gamma is not None else 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dout.device) if nbytes else None
+    PROFILE.call("eve_scale_residual_bwd", _p(dout), _p(x), _p(gamma), _p(row_scale), _p(dx), _p(dgamma), S, T, M, _dt(dout),
+                 _p(ws), nbytes, _stream())
+    return dx, dgamma

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 7
+#define EVE_MOE_ABI_VERSION 8
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -327,6 +327,24 @@ int eve_split_ln_bwd(const void* dxg, const void* h, const float* mean, const fl
  * torch.cat at :366-370).  It is its own transpose, so each direction is the other's backward. */
 int eve_split_permute(const void* src, void* dst, int B, int T, int n_vis, int R, int M, int to_groups, int dtype,
                       void* stream);
+
+/* ------------------------------------------------ layer-scale residual branch of the encoder layer
+ * out = residual + (x * gamma) * row_scale[s / T]: `residual + self.drop_path(hidden_states * self.gamma_1)` and
+ * `... * self.gamma_2` of MultiwayTransformerEnocderLayer.forward (models/multiway_transformer.py:341, :408) in ONE
+ * pass over the rows instead of a multiply, the DropPath multiply and an add.  x, residual, out [S,M]; gamma [M]
+ * (NULL: layer scale off); row_scale [S/T] = mask / keep_prob of DropPath per sample (NULL: eval mode or
+ * drop_prob 0); all of `dtype`.  The products and the sum are rounded separately in fp32 (the reference's op chain
+ * bit for bit in fp32; bf16 rounds once at the end). */
+int eve_scale_residual_fwd(const void* x, const void* gamma, const void* row_scale, const void* residual, void* out, int S,
+                           int T, int M, int dtype, void* stream);
+
+/* Backward w.r.t. x and gamma (the gradient w.r.t. residual is dout itself): dx = (dout * row_scale) * gamma [S,M],
+ * dgamma [M] fp32 = column sums of (dout * row_scale) * x (two-stage fixed-order reduction, deterministic;
+ * workspace: eve_scale_residual_workspace_bytes).  gamma NULL: dx = dout * row_scale, no dgamma, no workspace. */
+size_t eve_scale_residual_workspace_bytes(int S, int M);
+int eve_scale_residual_bwd(const void* dout, const void* x, const void* gamma, const void* row_scale, void* dx,
+                           float* dgamma, int S, int T, int M, int dtype, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 #ifdef __cplusplus
 }

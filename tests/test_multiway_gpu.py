@@ -125,3 +125,66 @@ def test_split_ffn_state_dict_names_and_errors():
         m(torch.zeros(1, 8, 64, device=DEV), mode="audio")
     with pytest.raises(ValueError):
         m(torch.zeros(1, 3, 64, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,M,use_gamma,use_drop", [(3, 7, 64, True, True), (4, 237, 768, True, False),
+                                                      (2, 33, 1024, True, True), (5, 9, 72, False, True),
+                                                      (2, 5, 4096, True, True)])
+def test_scale_residual_matches_the_reference_op_chain(dtype, B, T, M, use_gamma, use_drop):
+    """eve_scale_residual_fwd/bwd vs `residual + drop_path(x * gamma)` (multiway_transformer.py:341, :408) in stock
+    torch ops: fp32 forward and dx bit for bit (same roundings in the same order), dgamma to summation order;
+    bf16 within one rounding."""
+    from eve_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(B * T + M)
+    x = torch.randn(B, T, M, generator=g).to(dtype).to(dev)
+    res = torch.randn(B, T, M, generator=g).to(dtype).to(dev)
+    dout = torch.randn(B, T, M, generator=g).to(dtype).to(dev)
+    gamma = (0.1 + 0.05 * torch.randn(M, generator=g)).to(dtype).to(dev) if use_gamma else None
+    rs = ((torch.rand(B, generator=g) < 0.7).float() / 0.7).to(dtype).to(dev) if use_drop else None
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True) if use_gamma else None
+    t = xr * gr if use_gamma else xr
+    if use_drop:
+        t = t * rs.view(B, 1, 1)
+    want = res + t
+    want.backward(dout)
+    S = B * T
+    out = ops.scale_residual_fwd(x.view(S, M), gamma, rs, res.view(S, M), T)
+    dx, dgamma = ops.scale_residual_bwd(dout.view(S, M), x.view(S, M), gamma, rs, T)
+    torch.cuda.synchronize()
+    if dtype == torch.float32:
+        assert torch.equal(out.view(B, T, M), want.detach())
+        assert torch.equal(dx.view(B, T, M), xr.grad)
+    else:
+        torch.testing.assert_close(out.view(B, T, M).float(), want.detach().float(), rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(dx.view(B, T, M).float(), xr.grad.float(), rtol=1e-2, atol=1e-2)
+    if use_gamma:
+        ref64 = ((dout.double() * (rs.double().view(B, 1, 1) if use_drop else 1.0)) * x.double()).sum((0, 1))
+        torch.testing.assert_close(dgamma.double(), ref64, rtol=1e-4, atol=1e-4 * float(ref64.abs().max()))
+    else:
+        assert dgamma is None
+
+
+def test_encoder_layer_residual_branch_with_drop_path_replays_the_draw():
+    """The fused residual branch consumes the generator exactly as DropPath does: same seed -> same masks as the
+    stock-op formulation, so outputs agree (bf16 rounding apart) in training mode with drop_path > 0."""
+    import eve_amd
+    from eve_amd.encoder import MultiwayTransformerEnocderLayer as Layer
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    layer = Layer(64, "quick_gelu", 4, 128, (5, 4), drop_path=0.4, use_ffn=False).to(dev).train()
+    x = torch.randn(6, 9, 64, device=dev)
+    torch.manual_seed(11)
+    got = layer(x, mode="vl")
+
+    def stock_branch(residual, h, gamma):
+        return residual + layer.drop_path(h * gamma)
+
+    torch.manual_seed(11)
+    layer._branch = stock_branch
+    want = layer(x, mode="vl")
+    del layer._branch
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -18,6 +18,7 @@ from eve_amd.encoder import MultiwayTransformerEnocderLayer
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--stock", action="store_true")
+ap.add_argument("--stock-branch", action="store_true", help="eve_amd FFN paths, residual + drop_path(x * gamma) as stock ops")
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
@@ -89,14 +90,21 @@ class StockLayer(MultiwayTransformerEnocderLayer):
             return stock_moe(self, h, mode)
         return stock_split(self, h, mode)
 
+    def _branch(self, residual, x, gamma):  # reference :341, :408 as three stock ops
+        return residual + self.drop_path(x * gamma)
+
+
+class StockBranchLayer(MultiwayTransformerEnocderLayer):  # A/B of the fused residual branch alone
+    _branch = StockLayer._branch
+
 
 enc = eve_amd.eve_base_encoder()
 if a.layers != 12:  # shorter stacks for quick runs: keep the last two (MoE) layers
     enc.layers = torch.nn.ModuleList(list(enc.layers)[12 - a.layers:])
 enc = enc.to(torch.bfloat16).to(dev).train()
-if a.stock:
+if a.stock or a.stock_branch:
     for l in enc.layers:
-        l.__class__ = StockLayer
+        l.__class__ = StockLayer if a.stock else StockBranchLayer
 B, T, M = a.batch, 237, 768
 g = torch.Generator().manual_seed(1)
 x0 = torch.randn(B, T, M, generator=g).to(torch.bfloat16).to(dev)
