@@ -63,6 +63,10 @@ alg = {  # kernel -> (algorithmic bytes, flops, note)
     "gate_select32_kernel": (12 * E * S, 0, "logits + draws in, gates out: 12E B/token"),
     "gate_assign32_kernel": (40 * S, 0, "idx/rank in, loc/slot/weight + slot maps out"),
     "dispatch_fwd_kernel": ((S + K) * M * b, 0, "(S+K)*M*b"),
+    "dispatch_fwd_tok_kernel": ((S + K) * M * b, 0, "(S+K)*M*b"),
+    "combine_fwd_np_kernel": ((S + K) * M * b, 0, "(K+S)*M*b"),
+    "combine_bwd_np_kernel": ((S + 2 * K) * M * b, 0, "(S+2K)*M*b"),
+    "route_bwd_bf16_kernel": ((S + K) * M * b, 2.0 * S * M * E, "(K+S)*M*b"),
     "combine_fwd_kernel": ((S + K) * M * b, 0, "(K+S)*M*b"),
     "combine_bwd_kernel": ((S + 2 * K) * M * b, 0, "(S+2K)*M*b"),
     "route_bwd_kernel": ((S + K) * M * b, 2.0 * S * M * E, "(K+S)*M*b"),
