@@ -1583,6 +1583,9 @@ static const Knobs& knobs() {
 #endif
   return k;
 }
+#ifdef EVE_PP_STAMP
+static int g_stamp_grid = 0;
+#endif
 static bool use_pingpong() { return knobs().pingpong; }
 // `shared` (EVE_FFN_SHARED_GPU of the call's flags): other kernels run beside this launch, so no persistent grid
 static bool use_persistent(bool shared) { return knobs().persist && !shared; }
@@ -1610,6 +1613,9 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, co
   constexpr int kStage = 8 * 16 * EPI_LD * 4;
   constexpr int kLdsP = (5 * 256 * BKI * 2 + kStage > 160 * 1024) ? 5 * 256 * BKI * 2 : 5 * 256 * BKI * 2 + kStage;
   dim3 grid(persist ? (cu_count() / 8) * 8 : pr.ntotal);
+#ifdef EVE_PP_STAMP
+  if (persist && g_stamp_grid > 0) grid = dim3(g_stamp_grid);  // diagnostic: fewer CUs at work (tools/pp_stamps.hip)
+#endif
 #define EVE_PP_LAUNCH(A)                                                                                     \
   do {                                                                                                       \
     auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                                \

@@ -121,6 +121,13 @@ static void run_p(const char* name, int G, int R, int N, int K, bool bcol, int a
 }
 
 int main(int argc, char** argv) {
+  if (argc > 2) {  // "p <nwg>": fc1 with half the groups on <nwg> workgroups -- the same work per CU, fewer CUs storing
+    g_stamp_grid = atoi(argv[2]);
+    run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act, G=32 on the override grid", 32, 948, 3072, 768, false, EVE_ACT_QUICK_GELU);
+    run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act, G=16 on the override grid", 16, 948, 3072, 768, false, EVE_ACT_QUICK_GELU);
+    run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act, G=8 on the override grid", 8, 948, 3072, 768, false, EVE_ACT_QUICK_GELU);
+    return 0;
+  }
   if (argc > 1) {  // persistent-kernel timelines
     run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act", 32, 948, 3072, 768, false, EVE_ACT_QUICK_GELU);
     run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act, K steps of tile 0", 32, 948, 3072, 768, false, EVE_ACT_QUICK_GELU, 0);
