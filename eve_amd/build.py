@@ -45,7 +45,14 @@ def _stale(out: str) -> bool:
     if not os.path.exists(out):
         return True
     t = os.path.getmtime(out)
-    return any(os.path.getmtime(d) > t for d in source_files())
+    if any(os.path.getmtime(d) > t for d in source_files()):
+        return True
+    # mtimes lie after a checkout or a copy: the digest recorded beside the library at link time must be the checkout's
+    try:
+        with open(out + ".digest") as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False, variant: str = "", defines=()) -> str:
@@ -83,6 +90,8 @@ def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False, 
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(out + ".digest", "w") as f:
+        f.write(digest + "\n")
     return out
 
 
