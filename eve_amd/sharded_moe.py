@@ -384,6 +384,34 @@ class _CombineFn(torch.autograd.Function):
         return dy, dw, None, None, None
 
 
+_cast_cache: Dict[int, tuple] = {}
+
+
+def _cast_cached(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
+    """`t.to(dtype).contiguous()` for a (small) parameter, re-made only when the parameter has changed: fp32 master
+    parameters with bf16 activations would otherwise pay a cast kernel per parameter and step.  Keyed by the tensor
+    object and its version counter (optimizers update in place and bump it; `.data` swaps change the storage pointer).
+    Never cached under graph capture: the cast must be a node of the graph so that replays see updated parameters."""
+    if t is None:
+        return None
+    if t.dtype == dtype:
+        return t if t.is_contiguous() else t.contiguous()
+    if torch.cuda.is_current_stream_capturing():
+        return t.to(dtype).contiguous()
+    import weakref
+    key = id(t)
+    hit = _cast_cache.get(key)
+    if hit is not None:
+        ref, version, ptr, dt, out = hit
+        if ref() is t and version == t._version and ptr == t.data_ptr() and dt == dtype:
+            return out
+    out = t.detach().to(dtype).contiguous()
+    if len(_cast_cache) > 256:
+        _cast_cache.clear()
+    _cast_cache[key] = (weakref.ref(t), t._version, t.data_ptr(), dtype, out)
+    return out
+
+
 _fused_plans: Dict[tuple, tuple] = {}
 
 
@@ -419,9 +447,9 @@ class _FusedMoEFn(torch.autograd.Function):
         B, T, M = h.shape
         S = B * T
         h2d = h.contiguous().view(S, M)
-        wg32 = wg.float().contiguous()
-        ve = None if vemb is None else vemb.to(h.dtype).contiguous()
-        te = None if temb is None else temb.to(h.dtype).contiguous()
+        wg32 = _cast_cached(wg, torch.float32)
+        ve = _cast_cached(vemb, h.dtype)
+        te = _cast_cached(temb, h.dtype)
         noise = noise.contiguous()
         E, I = wg32.shape[0], w1.shape[1]
         for t, n in ((w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (ve, "vision_embed"), (te, "text_embed")):

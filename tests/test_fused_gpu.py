@@ -110,3 +110,28 @@ def test_fused_entry_points_reject_small_buffers_and_bad_shapes():
     big = _lib.MoEShape(S, T, 3, _lib.MODE_VL, M, I, 64, C, _lib.ACT_QUICK_GELU, _lib.BF16, _lib.BF16)
     assert fwd(1 << 30, 1 << 30, ctypes.addressof(big)) == -4
     assert lib.eve_moe_workspace_bytes(ref, 7) == 0
+
+
+def test_cached_parameter_casts_follow_in_place_updates():
+    """fp32 modality embeddings with bf16 activations: the fused path keeps a cast copy per parameter version; an
+    optimizer-style in-place update must be seen by the next forward (same results as the per-stage path, which casts
+    every call)."""
+    M, I, E, B, T, n_vis = 64, 128, 8, 4, 11, 6
+    p = orc.make_params(M, I, E, seed=5)
+    moe = build_moe(p, M, I, E, n_vis, device=DEV)
+    moe.moe.experts.to(torch.bfloat16)  # experts bf16, gate + embeddings stay fp32 parameters
+    g = torch.Generator().manual_seed(2)
+    h = torch.randn(B, T, M, generator=g).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B, T, M, generator=g).to(torch.bfloat16).to(DEV)
+    noise = orc.gumbel_noise((B * T, E), generator=g).to(DEV)
+    for step in range(3):
+        a = _run(moe, h, dout, noise, "vl", fused=True)
+        b = _run(moe, h, dout, noise, "vl", fused=False)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert (x is None) == (y is None), (step, i)
+            if x is not None:
+                assert x.dtype == y.dtype and torch.equal(x, y), f"step {step}: result {i} differs"
+        with torch.no_grad():  # what an optimizer does: in place, bumps the version counter
+            moe.moe.vision_embed.add_(0.05)
+            moe.moe.text_embed.mul_(1.5)
+            moe.moe.gate.wg.weight.add_(0.01 * torch.randn_like(moe.moe.gate.wg.weight))
