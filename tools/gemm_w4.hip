@@ -16,6 +16,10 @@ using namespace eve;
 
 constexpr int W4_BM = 256, W4_BN = 256, W4_STAGE = (W4_BM + W4_BN) * BK * 2;  // 64 KiB per K step
 
+// v2: a ring of ten 16 KiB sub-tiles (128 rows x 64 k: A top / A bottom / B left / B right of a K step, in that order),
+// so that a wave's 16 LDS-DMA pieces per step are spread one per four MFMAs (scheduling fences pin the order) and a
+// sub-tile has most of a step to land: during step t the pieces of B(t+1) go out first, then those of A(t+2).
+constexpr int W4_SUB = 128 * BK * 2, W4_NSLOT = 10;
 __global__ __launch_bounds__(256) void gemm_w4_kernel(MfmaDesc d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -29,15 +33,22 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(MfmaDesc d) {
   const bf16_t* Bg = d.B + (size_t)(z % d.E_local) * d.b_g;
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag), 0, (uint32_t)(d.Mext * d.lda) * 2u, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bg), 0, (uint32_t)(d.N * d.ldb) * 2u, 0x00020000);
-  uint32_t va[8], vb[8];
-  tile_dma_offsets<false, W4_BM, 4>(d.lda, wave, lane, va);
-  tile_dma_offsets<false, W4_BN, 4>(d.ldb, wave, lane, vb);
-  const uint32_t oa = (uint32_t)(m0 * d.lda) * 2u, ob = (uint32_t)(n0 * d.ldb) * 2u;
+  uint32_t va[4], vb[4];  // per-lane offsets of this wave's 4 pieces of a 128-row sub-tile
+  tile_dma_offsets<false, 128, 4>(d.lda, wave, lane, va);
+  tile_dma_offsets<false, 128, 4>(d.ldb, wave, lane, vb);
   const int nk = d.K / BK;
-  auto fetch = [&](int t) {
-    char* st = smem + (t & 1) * W4_STAGE;
-    tile_dma<W4_BM, 4>(ra, oa + (uint32_t)t * BK * 2u, va, st, wave);
-    tile_dma<W4_BN, 4>(rb, ob + (uint32_t)t * BK * 2u, vb, st + W4_BM * BK * 2, wave);
+  // piece i (0..3) of sub-tile q of the sequence: q = 4 t + part, part 0 / 1 = A rows 0.. / 128.., 2 / 3 = B cols 0.. / 128..
+  auto piece = [&](int q, int i) {
+    const int t = q >> 2, part = q & 3;
+    char* slot = smem + (q % W4_NSLOT) * W4_SUB;
+    const uint32_t kofs = (uint32_t)t * BK * 2u;
+    if (part < 2) {
+      const uint32_t org = (uint32_t)((m0 + part * 128) * d.lda) * 2u + kofs;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, va[i] + org, 0, 0, 0);
+    } else {
+      const uint32_t org = (uint32_t)((n0 + (part - 2) * 128) * d.ldb) * 2u + kofs;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, vb[i] + org, 0, 0, 0);
+    }
   };
   f32x16 acc[4][4];
 #pragma unroll
@@ -46,59 +57,42 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(MfmaDesc d) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  fetch(0);
+  for (int q = 0; q < 6; ++q)  // steps 0 and the A half of step 1; the steady state keeps 6 sub-tiles ahead
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece(q, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   bf16x8 fa[2][4], fb[2][4];
   for (int t = 0; t < nk; ++t) {
-    const char* sa = smem + (t & 1) * W4_STAGE;
-    const char* sb = sa + W4_BM * BK * 2;
-#ifdef W4_NOREAD
-    if (t == 0) {
-#endif
+    const char* sa = smem + ((4 * t + wm) % W4_NSLOT) * W4_SUB;       // my 128 rows of A(t)
+    const char* sb = smem + ((4 * t + 2 + wn) % W4_NSLOT) * W4_SUB;   // my 128 columns of B(t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[0][i] = frag_load<false, W4_BM>(sa, wm * 128 + i * 32, 0, lane);
+    for (int i = 0; i < 4; ++i) fa[0][i] = frag_load<false, 128>(sa, i * 32, 0, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb[0][j] = frag_load<false, W4_BN>(sb, wn * 128 + j * 32, 0, lane);
-#ifdef W4_NOREAD
-    }
-#endif
-#ifndef W4_NODMA
-    fetch(t + 1);  // unconditional (past the last step the descriptor's extent makes it a zero fill): no branch in the step
-#endif
+    for (int j = 0; j < 4; ++j) fb[0][j] = frag_load<false, 128>(sb, j * 32, 0, lane);
+    const int qn = 4 * t + 6;  // sub-tiles fetched during this step: B(t+1) left / right, A(t+2) top / bottom
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
-#ifdef W4_NOREAD
-      if (t == 0 && ks + 1 < 4) {  // diagnostic: the MFMA stream alone (stale fragments after the first step)
-#else
-      if (ks + 1 < 4) {
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[nxt][i] = frag_load<false, W4_BM>(sa, wm * 128 + i * 32, ks + 1, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[nxt][j] = frag_load<false, W4_BN>(sb, wn * 128 + j * 32, ks + 1, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-#ifdef W4_SCHED
-      // 16 MFMAs and 8 LDS reads per sub-step: one read behind every second MFMA
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read: one LDS-DMA piece of the next K step
+        __builtin_amdgcn_sched_barrier(0);
+        piece(qn + ks, g);  // past the end of K the descriptor's extent turns it into a zero fill
+        if (ks + 1 < 4) {
+          fa[nxt][g] = frag_load<false, 128>(sa, g * 32, ks + 1, lane);
+          fb[nxt][g] = frag_load<false, 128>(sb, g * 32, ks + 1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][g], fb[cur][j], acc[g][j], 0, 0, 0);
       }
-#endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything but this step's last two sub-tiles (A(t+2)) has landed
     __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // plain epilogue (prototype: scalar bf16 stores straight from the accumulators)
   bf16_t* Cg = d.C + (size_t)z * d.c_g;
   const int c = lane & 31, hh = lane >> 5;
@@ -151,7 +145,7 @@ int main() {
   printf("library 192-row ping-pong : %7.1f us  %6.0f TFLOP/s (%s)\n", ms * 1000 / 50, flops / (ms / 50 * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
   d.C = C;
   const int tiles = G * ((R + W4_BM - 1) / W4_BM) * (N / W4_BN);
-  const int lds = 2 * W4_STAGE;
+  const int lds = W4_NSLOT * W4_SUB;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
     printf("cannot reserve LDS\n");
     return 1;
