@@ -228,7 +228,7 @@ def other_configs(dev, steps=10, warmup=4):
     return out
 
 
-def encoder12(dev, steps=5, warmup=2):
+def encoder12(dev, steps=8, warmup=4):
     """BASELINE.json configs[1] as a whole: EVE-Base 12-layer encoder (MoE in layers 10-11, hard modality split in the
     others, stock fused attention), batch 64 x 237 tokens, bf16, fwd+bwd incl. the gate loss."""
     import eve_amd
