@@ -716,9 +716,11 @@ __global__ __launch_bounds__(256) void route_bwd_bf16_kernel(const bf16_t* __res
       float* g = img + tok * kRwLd + 8 * ch;
       const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
       const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      if (sl[i].x < 0) v1[i] = zero16<bf16_t>();  // row 0 stood in for "no slot": one select per chunk, not per element
+      if (sl[i].y < 0) v2[i] = zero16<bf16_t>();
       float ov[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ov[j] = (gv[j] + (sl[i].x >= 0 ? v1[i].get(j) : 0.f)) + (sl[i].y >= 0 ? v2[i].get(j) : 0.f);
+      for (int j = 0; j < 8; ++j) ov[j] = (gv[j] + v1[i].get(j)) + v2[i].get(j);
       Vec16<bf16_t> o;
       o.set_all(ov);
       const bool live = s < S;
@@ -736,10 +738,18 @@ __global__ __launch_bounds__(256) void route_bwd_bf16_kernel(const bf16_t* __res
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       float av = 0.f, at = 0.f;
+      const unsigned livem = s0 + 32 <= S ? 0xffffffffu : ((1u << (S - s0)) - 1u);  // rows past the end hold zeros
+      if (tm == 0u || tm == livem) {  // one modality in the item (most items): a plain sum, same order
+        float a = 0.f;
 #pragma unroll 8
-      for (int tt = 0; tt < 32; ++tt) {
-        const float x = img[tt * kRwLd + lane];
-        if ((tm >> tt) & 1u) at += x; else av += x;
+        for (int tt = 0; tt < 32; ++tt) a += img[tt * kRwLd + lane];
+        if (tm == 0u) av = a; else at = a;
+      } else {
+#pragma unroll 8
+        for (int tt = 0; tt < 32; ++tt) {
+          const float x = img[tt * kRwLd + lane];
+          if ((tm >> tt) & 1u) at += x; else av += x;
+        }
       }
       if (c0 + lane < M) {
         part[((size_t)grp_c * 2 + 0) * M + c0 + lane] = av;
