@@ -27,7 +27,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(MfmaDesc d) {
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_m = (d.Mext + W4_BM - 1) / W4_BM, tiles_n = d.N / W4_BN;
   const int per_group = tiles_m * tiles_n;
-  const int z = blockIdx.x / per_group, tile = blockIdx.x % per_group;
+#ifdef W4_PLAIN_ORDER
+  const int item = blockIdx.x;
+#else
+  // the library's XCD-aware order: block b runs on XCD b % 8, each XCD walks a contiguous run of (expert, tile) items
+  const int per_xcd = (d.G * per_group + 7) >> 3;
+  const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || item >= d.G * per_group) return;
+#endif
+  const int z = item / per_group, tile = item % per_group;
   const int m0 = (tile % tiles_m) * W4_BM, n0 = (tile / tiles_m) * W4_BN;
   const bf16_t* Ag = d.A + (size_t)z * d.a_g;
   const bf16_t* Bg = d.B + (size_t)(z % d.E_local) * d.b_g;
@@ -41,7 +49,11 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(MfmaDesc d) {
   auto piece = [&](int q, int i) {
     const int t = q >> 2, part = q & 3;
     char* slot = smem + (q % W4_NSLOT) * W4_SUB;
+#ifdef W4_SAMEK
+    const uint32_t kofs = 0;  // diagnostic: every step fetches K tile 0 (hits in L2): is the fetch latency the cost?
+#else
     const uint32_t kofs = (uint32_t)t * BK * 2u;
+#endif
     if (part < 2) {
       const uint32_t org = (uint32_t)((m0 + part * 128) * d.lda) * 2u + kofs;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, va[i] + org, 0, 0, 0);
