@@ -79,7 +79,7 @@ struct MfmaDesc {
   float* dbias_part;
   // MEPI_DACT launches: column sums of the OUTPUT (dz) for the bias gradient db1, taken in the epilogue while the
   // values are in registers: fp32 partials colsum[(z * colsum_slots + slot) * N + n], slot = wave row block of the
-  // group (m0 / rows-per-wave + wave row); colsum_reduce_kernel adds them up in a fixed order.  nullptr = off.
+  // group (m0 / rows-per-wave + wave row); bias_grads_kernel adds them up in a fixed order.  nullptr = off.
   float* colsum;
   int colsum_slots;
 #ifdef EVE_PP_STAMP
@@ -1423,42 +1423,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *reinterpret_cast<uint4*>(out + i) = pack8(v);
 }
 
-// db[e][n] = bf16(sum over the groups g = seg * E_local + e that share expert e and over the wave row blocks
-// ("slots") that the MEPI_DACT launch wrote for g, of part[(g * slots + s) * N + n]); fixed order.  Slots of
-// tiles the launch skipped (first row at or beyond rows[g]) were never written and are not read.
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, bf16_t* __restrict__ out,
-                                                            const int32_t* __restrict__ rows, int G, int E_local, int R,
-                                                            int N, int slots, int tile_rows, int spt) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
-  if (n >= N) return;
-  float acc = 0.f;
-  for (int g = e; g < G; g += E_local) {
-    const int mext = rows ? min(R, rows[g]) : R;
-    const int valid = (mext + tile_rows - 1) / tile_rows * spt;
-    for (int sl = 0; sl < valid; ++sl) acc += part[((size_t)g * slots + sl) * N + n];
-  }
-  out[(size_t)e * N + n] = static_cast<bf16_t>(acc);
-}
-
-// out[e][c] = bf16(sum over the groups g that share expert e and rows r < rows[g] of x[g][r][c]) for a row-major
-// [G, R, N] bf16 tensor: the bias gradient db2 = column sums of dy.  Block = 64 columns (8 chunks of 16 B) x 128
-// row lanes; each thread walks its rows in order (two loads in flight), the row lanes are added through LDS in order.
-__global__ __launch_bounds__(1024) void rows_colsum_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
-                                                           const int32_t* __restrict__ rows, int G, int E_local, int R, int N) {
+// Both bias gradients of the ping-pong path in ONE launch (they sit between the dz and the dx GEMM, where a launch
+// of a few microseconds is pure latency): blocks [0, nb2) form db2, the rest db1.
+//   db2: out2[e][c] = bf16(sum over the groups g that share expert e and rows r < rows[g] of dy[g][r][c]), dy a
+//        row-major [G, R, M] bf16 tensor.  Block = 64 columns (8 chunks of 16 B) x 128 row lanes; each thread walks
+//        its rows in order (two loads in flight), the row lanes are added through LDS in order.
+//   db1: out1[e][n] = bf16(sum over the groups g = seg * E_local + e and over the wave row blocks ("slots") that the
+//        MEPI_DACT launch wrote for g, of part[(g * slots + s) * I + n]); fixed order.  Slots of tiles the launch
+//        skipped (first row at or beyond rows[g]) were never written and are not read.  Block = 1024 columns.
+__global__ __launch_bounds__(1024) void bias_grads_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ out2,
+                                                          const float* __restrict__ part, bf16_t* __restrict__ out1,
+                                                          const int32_t* __restrict__ rows, int G, int E_local, int R,
+                                                          int M, int I, int slots, int tile_rows, int spt, int nb2) {
   __shared__ float red[128][64 + 1];
-  const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3, e = blockIdx.y;
-  const int col = blockIdx.x * 64 + ch * 8;
+  if ((int)blockIdx.x >= nb2) {
+    const int b = blockIdx.x - nb2, per_e = (I + 1023) / 1024;
+    const int n = (b % per_e) * 1024 + threadIdx.x, e = b / per_e;
+    if (n >= I) return;
+    float acc = 0.f;
+    for (int g = e; g < G; g += E_local) {
+      const int mext = rows ? min(R, rows[g]) : R;
+      const int valid = (mext + tile_rows - 1) / tile_rows * spt;
+      for (int sl = 0; sl < valid; ++sl) acc += part[((size_t)g * slots + sl) * I + n];
+    }
+    out1[(size_t)e * I + n] = static_cast<bf16_t>(acc);
+    return;
+  }
+  const int per_e = (M + 63) / 64;
+  const int bx = blockIdx.x % per_e, e = blockIdx.x / per_e;
+  const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int col = bx * 64 + ch * 8;
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  if (col < N) {
+  if (col < M) {
     for (int g = e; g < G; g += E_local) {
       const int mext = rows ? min(R, rows[g]) : R;
-      const bf16_t* xg = x + (size_t)g * R * N + col;
+      const bf16_t* xg = dy + (size_t)g * R * M + col;
       int r = rl;
       for (; r + 128 < mext; r += 256) {
-        const uint4 v0 = *reinterpret_cast<const uint4*>(xg + (size_t)r * N);
-        const uint4 v1 = *reinterpret_cast<const uint4*>(xg + (size_t)(r + 128) * N);
+        const uint4 v0 = *reinterpret_cast<const uint4*>(xg + (size_t)r * M);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(xg + (size_t)(r + 128) * M);
         const uint32_t *w0 = &v0.x, *w1 = &v1.x;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += bf16_bits_to_f32(w0[j >> 1], j & 1);
@@ -1466,7 +1471,7 @@ __global__ __launch_bounds__(1024) void rows_colsum_kernel(const bf16_t* __restr
         for (int j = 0; j < 8; ++j) acc[j] += bf16_bits_to_f32(w1[j >> 1], j & 1);
       }
       if (r < mext) {
-        const uint4 v0 = *reinterpret_cast<const uint4*>(xg + (size_t)r * N);
+        const uint4 v0 = *reinterpret_cast<const uint4*>(xg + (size_t)r * M);
         const uint32_t* w0 = &v0.x;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += bf16_bits_to_f32(w0[j >> 1], j & 1);
@@ -1479,8 +1484,8 @@ __global__ __launch_bounds__(1024) void rows_colsum_kernel(const bf16_t* __restr
   if (threadIdx.x < 64) {
     float sum = 0.f;
     for (int r = 0; r < 128; ++r) sum += red[r][threadIdx.x];
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < N) out[(size_t)e * N + c] = static_cast<bf16_t>(sum);
+    const int c = bx * 64 + threadIdx.x;
+    if (c < M) out2[(size_t)e * M + c] = static_cast<bf16_t>(sum);
   }
 }
 
@@ -1740,8 +1745,8 @@ static int wgrad_ksplit(int G, int E_local, int M, int I) {
 // Bias gradients of the ping-pong path are formed outside the weight-gradient GEMMs (whose bias-gradient tiles had
 // to run a 32-deep body at about half the MFMA rate: a third of the dw1 tiles, a twelfth of the dw2 tiles):
 //   db1 = column sums of dz: partial sums per wave row block, taken in the MEPI_DACT epilogue while dz is in
-//         registers (fp32, before rounding), then colsum_reduce_kernel;
-//   db2 = column sums of dy: rows_colsum_kernel over the (L2 / Infinity-Cache resident) gradient rows.
+//         registers (fp32, before rounding), summed by bias_grads_kernel;
+//   db2 = column sums of dy: the same launch, over the (L2 / Infinity-Cache resident) gradient rows.
 // Partial slots per group: one per wave row block; 96 rows is the smallest wave row block of a ping-pong tile.
 static size_t colsum_bytes(int G, int R, int I) { return align_up((size_t)G * (ceil_div(R, 96) + 1) * I * sizeof(float), 256); }
 
@@ -1787,11 +1792,10 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   (void)wave_rows;
   if (int rc = launch<false, true, MEPI_DACT, false, false>(d, act, st, shared)) return rc;
   if (pp) {  // db1 from the partials, db2 from dy
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(I, 256), E_local), dim3(256), 0, st, colsum, (bf16_t*)db1, rows, G,
-                       E_local, R, I, d.colsum_slots, tc.rows, tc.spt);
-    hipLaunchKernelGGL(rows_colsum_kernel, dim3(ceil_div(M, 64), E_local), dim3(1024), 0, st, (const bf16_t*)dy, (bf16_t*)db2,
-                       rows, G, E_local, R, M);
-    EVE_CHECK_LAUNCH("colsum_reduce_kernel / rows_colsum_kernel");
+    const int nb2 = ceil_div(M, 64) * E_local, nb1 = ceil_div(I, 1024) * E_local;
+    hipLaunchKernelGGL(bias_grads_kernel, dim3(nb2 + nb1), dim3(1024), 0, st, (const bf16_t*)dy, (bf16_t*)db2, colsum,
+                       (bf16_t*)db1, rows, G, E_local, R, M, I, d.colsum_slots, tc.rows, tc.spt, nb2);
+    EVE_CHECK_LAUNCH("bias_grads_kernel");
   }
   d.colsum = nullptr;
   // dx = dz @ w1: A = dz [R,I] row-major, B = w1 [I,M] k-major
