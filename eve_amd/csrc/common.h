@@ -126,4 +126,11 @@ __device__ __forceinline__ int token_modality(int s, int T, int n_vis, int mode)
   return (s % T) < n_vis ? 0 : 1;
 }
 
+// permute.hip: the closing stage of the fused backward (eve_moe_bwd), eve_route_bwd + eve_gate_wgrad in two launches
+bool route_wgrad_fusable(const void* dxd, const int32_t* slot, const void* dh, const void* h, int M, int E, int dtype);
+int route_bwd_gate_wgrad(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh, void* dvision,
+                         void* dtext, const void* h, const void* vision_embed, const void* text_embed, float* dwg, int S, int T,
+                         int n_vis, int mode, int M, int E, int embed_dtype, void* ws_embed, size_t ws_embed_bytes,
+                         void* ws_wgrad, size_t ws_wgrad_bytes, void* stream);
+
 }  // namespace eve

@@ -197,6 +197,13 @@ extern "C" int eve_moe_bwd(const eve_moe_shape* p, const void* dout, const float
   if (int rc = eve_gate_top2_bwd(gates, idx, loc, dweight, d_l_aux, exp_counts, p->S, p->E, p->C, dlogits, stream)) return rc;
   const bool want_v = dvision && (p->mode == EVE_MODE_VL || p->mode == EVE_MODE_VISION);
   const bool want_t = dtext && (p->mode == EVE_MODE_VL || p->mode == EVE_MODE_TEXT);
+  // route backward and gate weight gradient are independent of each other: one launch for both, one for their closing
+  // sums, where the shape takes the kernels that combine (bit-identical to the two calls below)
+  if (dwg && route_wgrad_fusable(dxd, slot, dh, h, p->M, p->E, p->dtype))
+    return route_bwd_gate_wgrad(dxd, slot, dlogits, wg, dh, want_v ? dvision : nullptr, want_t ? dtext : nullptr, h, vision_embed,
+                                text_embed, dwg, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->embed_dtype, w + ws.off[WS_EMBED],
+                                eve_embed_grad_workspace_bytes(p->S, p->M), w + ws.off[WS_WGRAD],
+                                eve_gate_wgrad_workspace_bytes(p->S, p->M, p->E), stream);
   if (int rc = eve_route_bwd(dxd, slot, dlogits, wg, dh, want_v ? dvision : nullptr, want_t ? dtext : nullptr, p->S, p->T, p->n_vis, p->mode,
                              p->M, p->E, p->dtype, p->embed_dtype, w + ws.off[WS_EMBED], eve_embed_grad_workspace_bytes(p->S, p->M), stream)) return rc;
   if (dwg) {

@@ -2,6 +2,7 @@
 // one-hot einsums (models/sharded_moe.py:367 and :377) and their autograd backward, plus the
 // modality-embedding gradient.  HBM-bound row movers: one wave per row, 16 B per lane.
 #include "common.h"
+#include "gate_wgrad_bf16.h"
 
 namespace eve {
 
@@ -613,21 +614,23 @@ __global__ __launch_bounds__(kRbThreads) void route_bwd_kernel(const T* __restri
 typedef __attribute__((ext_vector_type(8))) __bf16 rw_bf16x8;
 constexpr int kRwCols = 64;   // columns of a wave's item = 2 MFMA tiles
 constexpr int kRwLd = 68;     // floats per token row of a wave's image (+4: rows start in different banks)
-__global__ __launch_bounds__(256) void route_bwd_bf16_kernel(const bf16_t* __restrict__ dxd, const int32_t* __restrict__ slot,
-                                                             const float* __restrict__ dlogits, const float* __restrict__ wg,
-                                                             bf16_t* __restrict__ dh, float* __restrict__ part, int S, int T_,
-                                                             int n_vis, int mode, int M, int E, int ngroups) {
+// (bx, by, gx) = the block's position and the x extent of the kernel's (gx, column spans) grid: the block / grid
+// indices of the kernel of its own, a block range of the launch that also carries the gate weight gradient's blocks.
+// wfrag: uint4[8 * 64], fragment (tile q, k step ks, hi/lo) x lane; image: float[4][32 * kRwLd]; both the block's.
+__device__ __forceinline__ void route_bwd_bf16_body(const bf16_t* __restrict__ dxd, const int32_t* __restrict__ slot,
+                                                    const float* __restrict__ dlogits, const float* __restrict__ wg,
+                                                    bf16_t* __restrict__ dh, float* __restrict__ part, int S, int T_,
+                                                    int n_vis, int mode, int M, int E, int ngroups, int bx, int by, int gx,
+                                                    uint4* wfrag, float (*image)[32 * kRwLd]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __shared__ uint4 wfrag[8 * 64];  // fragment (tile q, k step ks, hi/lo) x lane
-  __shared__ __attribute__((aligned(16))) float image[4][32 * kRwLd];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const int c0 = blockIdx.y * kRwCols;
+  const int c0 = by * kRwCols;
   const int t = lane & 31, hh = lane >> 5;  // MFMA view: token t, accumulator half hh
   const int tq = lane >> 3, ch = lane & 7;  // row view: tokens 8 i + tq (i < 4), 16-byte chunk ch of the 64 columns
   const int colr = min(c0 + 8 * ch, M - 8);
   const bool col_ok = c0 + 8 * ch < M;
-  int grp = blockIdx.x * 4 + wave;
-  const int gstride = gridDim.x * 4;
+  int grp = bx * 4 + wave;
+  const int gstride = gx * 4;
   int2 sl[4];
   Vec16<bf16_t> v1[4], v2[4];
   float4 dl4[4];
@@ -762,13 +765,49 @@ __global__ __launch_bounds__(256) void route_bwd_bf16_kernel(const bf16_t* __res
 #endif
 }
 
-// fixed-order sum of the per-block partials: block = 32 columns x 32 slices of the partial rows
+__global__ __launch_bounds__(256) void route_bwd_bf16_kernel(const bf16_t* __restrict__ dxd, const int32_t* __restrict__ slot,
+                                                             const float* __restrict__ dlogits, const float* __restrict__ wg,
+                                                             bf16_t* __restrict__ dh, float* __restrict__ part, int S, int T_,
+                                                             int n_vis, int mode, int M, int E, int ngroups) {
+  __shared__ uint4 wfrag[8 * 64];
+  __shared__ __attribute__((aligned(16))) float image[4][32 * kRwLd];
+  route_bwd_bf16_body(dxd, slot, dlogits, wg, dh, part, S, T_, n_vis, mode, M, E, ngroups, blockIdx.x, blockIdx.y,
+                      gridDim.x, wfrag, image);
+}
+
+// The route backward and the gate weight gradient in ONE launch (the fused eve_moe_bwd): both only need dlogits, each
+// on its own is bound by its latency chain (37 % / 20 % of the HBM rate, waves parked half of their time), so their
+// blocks are dealt into one grid -- evenly interleaved, nw weight-gradient blocks among nr route blocks -- and fill
+// each other's waits.  Same bodies, same arithmetic, same results as the two kernels of their own.
+struct RouteWgradArgs {
+  const bf16_t* dxd; const int32_t* slot; const float* dlogits; const float* wg; bf16_t* dh; float* part_embed;
+  const bf16_t* h; const bf16_t* vemb; const bf16_t* temb; float* part_wg;
+  int S, T, n_vis, mode, M, E, ngroups;
+  int rbx, nr;    // route blocks: (rbx, column spans) flattened, nr of them
+  int wbx, nw;    // weight-gradient blocks: (wbx token chunks, groups of 256 columns) flattened, nw of them
+};
+template <bool EMB>
+__global__ __launch_bounds__(256) void route_wgrad_bf16_kernel(RouteWgradArgs a) {
+  __shared__ uint4 wfrag[8 * 64];
+  __shared__ __attribute__((aligned(16))) float image[4][32 * kRwLd];
+  const unsigned b = blockIdx.x, total = (unsigned)(a.nr + a.nw);
+  const unsigned w0 = (unsigned)((unsigned long long)b * a.nw / total), w1 = (unsigned)((unsigned long long)(b + 1) * a.nw / total);
+  if (w1 > w0) {  // weight-gradient block number w0
+    gate_wgrad_bf16_body<EMB>(a.h, a.vemb, a.temb, a.dlogits, a.part_wg, a.S, a.T, a.n_vis, a.mode, a.M, a.E, kWgradBf16TS,
+                              (int)(w0 % a.wbx), (int)(w0 / a.wbx));
+  } else {        // route block number b - w0
+    const unsigned r = b - w0;
+    route_bwd_bf16_body(a.dxd, a.slot, a.dlogits, a.wg, a.dh, a.part_embed, a.S, a.T, a.n_vis, a.mode, a.M, a.E, a.ngroups,
+                        (int)(r % a.rbx), (int)(r / a.rbx), a.rbx, wfrag, image);
+  }
+}
+
+// fixed-order sum of the per-block partials: block bx = 32 columns x 32 slices of the partial rows (`red`: float[32][33])
 template <typename TO>
-__global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* __restrict__ part, TO* __restrict__ dv,
-                                                                  TO* __restrict__ dt, int M, int nchunks) {
-  __shared__ float red[32][33];
+__device__ __forceinline__ void embed_grad_final32_body(const float* __restrict__ part, TO* __restrict__ dv,
+                                                        TO* __restrict__ dt, int M, int nchunks, int bx, float (*red)[33]) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + tx;   // over 2*M columns: [vision M | text M] per chunk row
+  const int col = bx * 32 + tx;   // over 2*M columns: [vision M | text M] per chunk row
   float acc = 0.f;
   if (col < 2 * M) {
 #pragma unroll 4
@@ -783,6 +822,26 @@ __global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* _
     if (col < M) { if (dv) dv[col] = from_f32<TO>(s); }
     else if (dt) dt[col - M] = from_f32<TO>(s);
   }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(1024) void embed_grad_final32_kernel(const float* __restrict__ part, TO* __restrict__ dv,
+                                                                  TO* __restrict__ dt, int M, int nchunks) {
+  __shared__ float red[32][33];
+  embed_grad_final32_body<TO>(part, dv, dt, M, nchunks, blockIdx.x, red);
+}
+
+// Both closing reductions of the fused backward in one launch: blocks [0, n1) the modality-embedding gradients
+// (embed_grad_final32), the rest the gate weight gradient's partial sums (sum_partials4: 64 outputs per block, on
+// the block's first 256 threads).
+template <typename TO>
+__global__ __launch_bounds__(1024) void final_sums_kernel(const float* __restrict__ part_embed, TO* __restrict__ dv,
+                                                          TO* __restrict__ dt, int M, int nchunks, int n1,
+                                                          const float* __restrict__ part_wg, float* __restrict__ dwg,
+                                                          int n_wg, int nparts_wg) {
+  __shared__ float red[32][33];
+  if ((int)blockIdx.x < n1) embed_grad_final32_body<TO>(part_embed, dv, dt, M, nchunks, blockIdx.x, red);
+  else sum_partials4_body(part_wg, dwg, n_wg, nparts_wg, (int)blockIdx.x - n1, reinterpret_cast<float(*)[64]>(&red[0][0]));
 }
 
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1054,3 +1113,60 @@ extern "C" int eve_route_bwd(const void* dxd, const int32_t* slot, const float* 
   }
   return EVE_OK;
 }
+
+namespace eve {
+
+// The fused backward's closing stage: eve_route_bwd + eve_gate_wgrad as TWO launches instead of four (see
+// route_wgrad_bf16_kernel / final_sums_kernel).  `route_wgrad_fusable` says whether the shape takes this path (the
+// same conditions under which the two entry points pick the kernels it combines); results are bit-identical to the
+// two calls.
+bool route_wgrad_fusable(const void* dxd, const int32_t* slot, const void* dh, const void* h, int M, int E, int dtype) {
+  return dtype == EVE_BF16 && E <= 32 && M % 8 == 0 && route_bwd_lds(M) <= 160 * 1024 && aligned_to(slot, 8) &&
+         aligned_to(dxd, 16) && aligned_to(dh, 16) && aligned_to(h, 4);
+}
+
+int route_bwd_gate_wgrad(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh, void* dvision,
+                         void* dtext, const void* h, const void* vision_embed, const void* text_embed, float* dwg, int S, int T,
+                         int n_vis, int mode, int M, int E, int embed_dtype, void* ws_embed, size_t ws_embed_bytes,
+                         void* ws_wgrad, size_t ws_wgrad_bytes, void* stream) {
+  EVE_REQUIRE(dxd && slot && dlogits && wg && dh && h && dwg && ws_wgrad, EVE_ERR_ARG, "eve_moe_bwd (route + gate wgrad): null pointer");
+  EVE_REQUIRE(embed_dtype == EVE_F32 || embed_dtype == EVE_BF16, EVE_ERR_ARG, "eve_moe_bwd: bad embed_dtype %d", embed_dtype);
+  EVE_REQUIRE(S > 0 && E > 0 && E <= 32 && M % 8 == 0, EVE_ERR_ARG, "eve_moe_bwd (route + gate wgrad): bad shape");
+  if (mode != EVE_MODE_NONE)
+    EVE_REQUIRE(vision_embed && text_embed && T > 0, EVE_ERR_ARG, "eve_moe_bwd (route + gate wgrad): embeddings required");
+  const bool want_embed = mode != EVE_MODE_NONE && (dvision || dtext);
+  if (want_embed) {
+    EVE_REQUIRE(S % T == 0, EVE_ERR_ARG, "eve_moe_bwd: S=%d not a multiple of T=%d", S, T);
+    const size_t need = eve_embed_grad_workspace_bytes(S, M);
+    EVE_REQUIRE(ws_embed && ws_embed_bytes >= need, EVE_ERR_WORKSPACE, "eve_moe_bwd: embed workspace %zu < %zu", ws_embed_bytes, need);
+  }
+  const size_t need_wg = eve_gate_wgrad_workspace_bytes(S, M, E);
+  EVE_REQUIRE(ws_wgrad_bytes >= need_wg, EVE_ERR_WORKSPACE, "eve_moe_bwd: gate wgrad workspace %zu < %zu", ws_wgrad_bytes, need_wg);
+  hipStream_t st = S_(stream);
+  RouteWgradArgs a;
+  a.dxd = (const bf16_t*)dxd; a.slot = slot; a.dlogits = dlogits; a.wg = wg; a.dh = (bf16_t*)dh;
+  a.part_embed = want_embed ? static_cast<float*>(ws_embed) : nullptr;
+  a.h = (const bf16_t*)h; a.vemb = (const bf16_t*)vision_embed; a.temb = (const bf16_t*)text_embed;
+  a.part_wg = static_cast<float*>(ws_wgrad);
+  a.S = S; a.T = T; a.n_vis = n_vis; a.mode = mode; a.M = M; a.E = E;
+  a.ngroups = ceil_div(S, kRbTok);
+  const int spans = ceil_div(M, kRwCols);
+  a.rbx = max(1, min(ceil_div(a.ngroups, 4), max(1, 768 / spans)));  // as eve_route_bwd
+  a.nr = a.rbx * spans;
+  a.wbx = ceil_div(S, kWgradBf16TS);                                  // as eve_gate_wgrad
+  a.nw = a.wbx * ceil_div(M, 256);
+  if (mode != EVE_MODE_NONE) hipLaunchKernelGGL(route_wgrad_bf16_kernel<true>, dim3(a.nr + a.nw), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(route_wgrad_bf16_kernel<false>, dim3(a.nr + a.nw), dim3(256), 0, st, a);
+  EVE_CHECK_LAUNCH("route_wgrad_bf16_kernel");
+  const int n1 = want_embed ? ceil_div(2 * M, 32) : 0, n2 = ceil_div(E * M, 64);
+  if (embed_dtype == EVE_F32)
+    hipLaunchKernelGGL(final_sums_kernel<float>, dim3(n1 + n2), dim3(1024), 0, st, a.part_embed, (float*)dvision, (float*)dtext, M,
+                       a.ngroups, n1, a.part_wg, dwg, E * M, a.wbx);
+  else
+    hipLaunchKernelGGL(final_sums_kernel<bf16_t>, dim3(n1 + n2), dim3(1024), 0, st, a.part_embed, (bf16_t*)dvision,
+                       (bf16_t*)dtext, M, a.ngroups, n1, a.part_wg, dwg, E * M, a.wbx);
+  EVE_CHECK_LAUNCH("final_sums_kernel");
+  return EVE_OK;
+}
+
+}  // namespace eve

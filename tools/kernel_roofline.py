@@ -73,6 +73,8 @@ alg = {  # kernel -> (algorithmic bytes, flops, note)
     "gate_wgrad_bf16_kernel": (S * M * b + 4 * S * E, 2.0 * S * M * E, "S*M*b + 4*S*E"),
     "gate_bwd32_kernel": (12 * E * S, 0, "gates, dlogits: ~12E B/token"),
     "bias_grads_kernel": (K * M * b, 0, "db2: dy rows in, K*M*b (+ the db1 partials, small)"),
+    "route_wgrad_bf16_kernel": ((2 * S + K) * M * b + 4 * S * E, 4.0 * S * M * E,
+                                "route_bwd (K+S)*M*b + gate_wgrad S*M*b + 4*S*E: the fused backward's combined launch"),
 }
 print(f"workload: {line['config']['workload']}")
 print(f"S = {S} tokens, K = {K} kept assignments, bench line: {line['ms_per_step']} ms/step, {line['value']:.0f} tokens/s")

@@ -52,3 +52,23 @@ timeit("combine_bwd", lambda: ops.combine_bwd(dout, y, r.slot, r.slot_token, r.s
 timeit("gate_top2_bwd", lambda: ops.gate_top2_bwd(r, dw, torch.ones(1, device=dev)), 12 * E * S)
 timeit("route_bwd", lambda: ops.route_bwd(dy, r.slot, dl, wg, S, T, n_vis, mode, True, True, torch.bfloat16), (S + K) * M * b)
 timeit("gate_wgrad", lambda: ops.gate_wgrad(h, ve, te, dl, T, n_vis, mode), S * M * b + 4 * S * E)
+if "--pair" in sys.argv:  # route_bwd and gate_wgrad (independent of each other) on two streams: what running them side by side buys
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def both():
+        cur = torch.cuda.current_stream()
+        s1.wait_stream(cur)
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            ops.route_bwd(dy, r.slot, dl, wg, S, T, n_vis, mode, True, True, torch.bfloat16)
+        with torch.cuda.stream(s2):
+            ops.gate_wgrad(h, ve, te, dl, T, n_vis, mode)
+        cur.wait_stream(s1)
+        cur.wait_stream(s2)
+
+    def serial():
+        ops.route_bwd(dy, r.slot, dl, wg, S, T, n_vis, mode, True, True, torch.bfloat16)
+        ops.gate_wgrad(h, ve, te, dl, T, n_vis, mode)
+
+    timeit("route_bwd ; gate_wgrad", serial, (2 * S + K) * M * b)
+    timeit("route_bwd || gate_wgrad", both, (2 * S + K) * M * b)
