@@ -257,12 +257,13 @@ def encoder12(dev, steps=8, warmup=4):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    enqueue_ms = (time.perf_counter() - t0) / steps * 1e3  # host time to issue a step: close to ms_per_step = host-bound
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     res = {"workload": "EVE-Base encoder, 12 layers, B=64 x (197 + 40) tokens, bf16, fwd+bwd (BASELINE configs[1]); attention "
                        "is PyTorch-ROCm's fused SDPA, the FFN branches are this library", "ms_per_step": round(ms, 3),
            "tokens_per_s": round(B * T / ms * 1e3, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-           "launch": "eager", "steps": steps}
+           "launch": "eager", "host_enqueue_ms_per_step": round(enqueue_ms, 3), "steps": steps}
     del enc, params
     torch.cuda.empty_cache()
     return res
