@@ -2,6 +2,10 @@
 // L / M phases of the first K tiles of two workgroups.  Not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Ieve_amd/csrc -DEVE_PP_STAMP -Wno-unused-const-variable \
 //         tools/pp_stamps.hip eve_amd/csrc/capi.hip -o tools/pp_stamps
+//   tools/pp_stamps x      per-tile / per-K-step timelines of the persistent kernel (what the library launches)
+//   tools/pp_stamps p 128  the same with the persistent grid cut to 128 workgroups
+//   tools/pp_stamps        the one-tile kernel's K-step stamps: only written when the launch takes that kernel, i.e. in a
+//                          build with -DEVE_FFN_DEBUG_KNOBS and EVE_FFN_PERSIST=0 in the environment (zeros otherwise)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
