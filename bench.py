@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3/4/5 and 12-layer encoder entries")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: after the timed region, check one expert-parallel step of every rank against the "
+                         "single-rank layer (all experts local) on the same batch and noise; adds `verify` to the line")
     return ap.parse_args()
 
 
@@ -172,6 +175,43 @@ def cpu_baseline(args, M, I, E, n_vis, T):
             "sample": f"B={B} of the {args.batch} sequences (S={B * T} tokens, EVE-{args.model} layer dims), fp32 dense "
                       f"one-hot/einsum port of the reference algorithm with per-expert leaf parameters, fwd+bwd, "
                       f"2 warm-up + {n} timed iterations"}
+
+
+def verify_against_single_rank(moe, h, dout, M, I, E, n_vis, dtype, dev, rank, world):
+    """One more step of the expert-parallel layer with a pinned Gumbel draw, and the same step on a single-rank layer
+    that holds all E experts (same parameters: build_layer seeds experts by their global index): a rank's own
+    tokens go through the same kernels row by row in both layouts, so output and input gradient must be bit-equal.
+    The flags are AND-ed over the ranks."""
+    from eve_amd import ops
+    S = h.shape[0] * h.shape[1]
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    noise = ops.gumbel_from_uniform(torch.rand(S, E, generator=g, device=dev))
+
+    def run(layer):
+        for p in layer.parameters():
+            p.grad = None
+        x = h.detach().requires_grad_(True)
+        layer.moe.noise_override = noise
+        out, l_aux, _ = layer(x, mode="vl")
+        torch.autograd.backward([out, l_aux], [dout, torch.ones_like(l_aux)])
+        torch.cuda.synchronize()
+        return out.detach(), x.grad, layer.moe.last_slot.clone()
+
+    out, dh, slot = run(moe)
+    one = build_layer(M, I, E, 1, 0, n_vis, dtype, dev)
+    out1, dh1, slot1 = run(one)
+    d_out = float((out.float() - out1.float()).abs().max())
+    d_dh = float((dh.float() - dh1.float()).abs().max())
+    flags = torch.tensor([float(torch.equal(out, out1)), float(torch.equal(dh, dh1)), float(torch.equal(slot, slot1)),
+                          -d_out, -d_dh], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    del one
+    torch.cuda.empty_cache()
+    f = flags.tolist()
+    return {"against": "single-rank layer (ep_size=1, all experts local), same batch and Gumbel draw, every rank",
+            "out_bit_equal": bool(f[0]), "dh_bit_equal": bool(f[1]), "routing_equal": bool(f[2]),
+            "max_abs_out_diff": -f[3], "max_abs_dh_diff": -f[4]}
 
 
 def time_layer(moe, h, dout, steps, warmup, train=True):
@@ -397,6 +437,10 @@ def main():
             roofline["note"] = ("expert parallel: every capacity row received is processed (E*C rows per rank, empty ones "
                                 "included); `achieved` counts kept rows only, `processed_tflops` all processed rows")
 
+    verify = None
+    if args.verify and world > 1:
+        verify = verify_against_single_rank(moe, h, dout, M, I, E, n_vis, dtype, dev, rank, world)
+
     if rank == 0:
         from eve_amd import _lib
         line = {
@@ -413,6 +457,8 @@ def main():
             "roofline": roofline,
             "phases_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }
+        if verify is not None:
+            line["verify"] = verify
         if rehearsal:
             line["rehearsal"] = "all ranks on cuda:0 over gloo with a host-staged exchange: NOT a measurement"
         if world == 1:
