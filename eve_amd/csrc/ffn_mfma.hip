@@ -82,6 +82,15 @@ struct MfmaDesc {
   // group (m0 / rows-per-wave + wave row); bias_grads_kernel adds them up in a fixed order.  nullptr = off.
   float* colsum;
   int colsum_slots;
+  // forward / dgrad launches with TWO groups of unequal height (the modality split: 12 608 vision rows beside
+  // 2 560 text rows): tiles are enumerated over the rows that exist (tile_of_block) instead of over
+  // G x ceil(Mext / BM) slots, most of which would be empty for the short group and leave its XCDs idle
+  int compact;
+  // weight-gradient launches of such groups (one K segment per expert, rows[] given): expert e's K range is cut
+  // into ceil(rows[e] / L) equal slices, L = ceil(sum of rows / kslots) -- at most kslots + E_local slices in all,
+  // numbered expert-major -- each with an fp32 partial Cpart[slice][Mext][N]; wgrad_reduce_dyn_kernel adds an
+  // expert's slices in order.  0 = off (ksplit decides).
+  int kslots;
 #ifdef EVE_PP_STAMP
   unsigned long long* dbg;  // diagnostic build (tools/pp_stamps.hip): [block 0 / 1000][wave 8][64] cycle stamps (low 32 bits)
   int same_tile;            // diagnostic: every K step fetches K tile 0 (everything hits in L2)
@@ -94,6 +103,66 @@ struct MfmaPair {
   int n0;      // blocks (tiles) of d[0]; a multiple of 8 (the XCD-aware tile order counts from each problem's first block)
   int ntotal;  // tiles of both problems (persistent kernel: the grid is smaller and walks them)
 };
+
+
+// ---- block id -> tile ------------------------------------------------------------------------------------
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so block b
+// and b+8 share an L2.  Every XCD walks a contiguous run of (group, tile) items -- whole groups when there are
+// at least 8 of them (sorted expert-major, so groups that share weights sit on one XCD), a slice of a group's
+// tiles when there are fewer -- and, inside a group, its tiles with the row tile varying fastest: the ~32 tiles
+// an XCD runs at a time then share their A row panels and B column panels through its L2 instead of each
+// streaming them from HBM.  (Speed only: correctness does not depend on where a block runs.)
+struct TileCoord { int z, split, m0, n0, mext; };
+
+__device__ __forceinline__ int dyn_slice_rows(const MfmaDesc& d) {
+  int total = 0;
+  for (int e = 0; e < d.E_local; ++e) total += min(d.K, d.rows[e]);
+  const int L = (total + d.kslots - 1) / d.kslots;
+  return max(64, (L + 63) & ~63);
+}
+__device__ __forceinline__ int dyn_nslices(int rows_e, int L) { return max(1, (rows_e + L - 1) / L); }
+
+// Forward / dgrad launches (and weight-gradient launches without dynamic slices): false = the block has no tile.
+// CMP: the compact enumeration (MfmaDesc::compact) -- a kernel variant of its own, so that the loops over rows[] do
+// not cost the many-group kernels registers.
+template <int BM, bool WGRAD, bool CMP = false>
+__device__ __forceinline__ bool tile_of_block(const MfmaDesc& d, unsigned bid, TileCoord& T) {
+  const int tiles_n = d.N / BN;
+  const int xcd = bid & 7, local = bid >> 3;
+  T.split = 0;
+  if constexpr (!WGRAD && CMP) {  // exactly two groups (closed form: no loop over rows[], two scalar loads)
+    const int mext0 = min(d.Mext, d.rows[0]), mext1 = min(d.Mext, d.rows[1]);
+    const int tm0 = (mext0 + BM - 1) / BM, tm1 = (mext1 + BM - 1) / BM;
+    const int cnt0 = tm0 * tiles_n, total = cnt0 + tm1 * tiles_n;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = xcd * per_xcd + local;
+    if (local >= per_xcd || item >= total) return false;
+    const bool g1 = item >= cnt0;
+    const int it = g1 ? item - cnt0 : item, tm = g1 ? tm1 : tm0;
+    T.z = g1 ? 1 : 0; T.m0 = (it % tm) * BM; T.n0 = (it / tm) * BN; T.mext = g1 ? mext1 : mext0;
+    return true;
+  }
+  const int tiles_m = (d.Mext + BM - 1) / BM;
+  const int tiles_per_group = tiles_m * tiles_n;
+  const int nsplit = WGRAD ? max(d.ksplit, 1) : 1;
+  const int ngroups = WGRAD ? d.E_local * nsplit : d.G;
+  const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
+  const int item = xcd * per_xcd + local;
+  if (local >= per_xcd || item >= ngroups * tiles_per_group) return false;
+  const int p = item / tiles_per_group;
+  const int tile = item % tiles_per_group;
+  if (WGRAD) {
+    T.z = p % d.E_local;   // p = split * E_local + expert
+    T.split = p / d.E_local;
+  } else {
+    const int ep = d.G / d.E_local;
+    T.z = (p % ep) * d.E_local + p / ep;  // p enumerates (expert, source) pairs expert-major
+  }
+  T.m0 = (tile % tiles_m) * BM; T.n0 = (tile / tiles_m) * BN;
+  T.mext = d.Mext;
+  if (!WGRAD && d.rows) T.mext = min(T.mext, d.rows[T.z]);
+  return T.m0 < T.mext;
+}
 
 // In-kernel cycle stamps, compiled only into the diagnostic build; they go to a buffer of their own.
 #ifdef EVE_PP_STAMP
@@ -498,34 +567,9 @@ __global__ __launch_bounds__((BM / 128) * 256) void grouped_gemm_mfma(MfmaDesc d
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wm = wave >> 2, wn = wave & 3;
-  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private
-  // L2), so block b and b+8 share an L2.  Every XCD walks a contiguous run of (group, tile) items --
-  // whole groups when there are at least 8 of them (sorted expert-major, so groups that share weights
-  // sit on one XCD), a slice of a group's tiles when there are fewer -- and, inside a group, its tiles
-  // with the row tile varying fastest: the ~32 tiles an XCD runs at a time then share their A row
-  // panels and B column panels through its L2 instead of each streaming them from HBM.
-  // (Speed only: correctness does not depend on where a block runs.)
-  const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
-  const int tiles_per_group = tiles_m * tiles_n;
-  const int ngroups = WGRAD ? d.E_local : d.G;
-  const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;  // each XCD walks a contiguous run of (group, tile) items
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int item = xcd * per_xcd + local;
-  if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
-  const int p = item / tiles_per_group;
-  const int tile = item % tiles_per_group;
-  int z;
-  if (WGRAD) {
-    z = p;
-  } else {
-    const int ep = d.G / d.E_local;
-    z = (p % ep) * d.E_local + p / ep;  // p enumerates (expert, source) pairs expert-major
-  }
-  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
-
-  int mext = d.Mext;
-  if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
-  if (m0 >= mext) return;
+  TileCoord tc;
+  if (!tile_of_block<BM, WGRAD>(d, blockIdx.x, tc)) return;  // XCD-aware tile order
+  const int z = tc.z, m0 = tc.m0, n0 = tc.n0, mext = tc.mext;
 
   f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -706,7 +750,7 @@ __device__ __forceinline__ uint32_t sub_dma_offset0(int ld, int w4, int lane) {
 }
 template <bool COL> __device__ __forceinline__ uint32_t sub_dma_stride(int ld) { return (uint32_t)(COL ? 8 : 32) * (uint32_t)ld * 2u; }
 
-template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
+template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR, bool CMP = false>
 __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // Two independent problems of the same kind may share a launch (the two weight-gradient GEMMs of a
@@ -730,29 +774,54 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int h = wave_u >> 2, w4 = wave_u & 3;  // half (= row half of the tile), index inside the half
   const int wm = wave >> 2, wn = wave & 3;
-  // XCD-aware tile order (see grouped_gemm_mfma)
-  const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
-  const int tiles_per_group = tiles_m * tiles_n;
-  const int nsplit = WGRAD ? max(d.ksplit, 1) : 1;
-  const int ngroups = WGRAD ? d.E_local * nsplit : d.G;
-  const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
-  const int xcd = bid & 7, local = bid >> 3;
-  const int item = xcd * per_xcd + local;
-  if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
-  const int p = item / tiles_per_group;
-  const int tile = item % tiles_per_group;
-  int z, split = 0;
-  if (WGRAD) {
-    z = p % d.E_local;   // p = split * E_local + expert
-    split = p / d.E_local;
+  // block -> tile (XCD-aware order, see tile_of_block) and, for weight gradients, the K range of the block:
+  // all segments (groups that share the expert) and all their rows, or -- split-K -- a run of whole segments
+  // (ksplit <= nseg) / one slice of one segment's rows (ksplit > nseg), or -- dynamic slices -- one of the
+  // ceil(rows[e] / L) equal slices of expert e's single segment
+  const int nseg = WGRAD ? d.G / d.E_local : 1;
+  int z, zpart, m0, n0, mext;
+  int seg_lo = 0, seg_hi = nseg, kbase = 0, kchunk = d.K;
+  if (WGRAD && d.kslots > 0) {
+    const int tiles_m = (d.Mext + BM - 1) / BM, tiles_per_group = tiles_m * (d.N / BN);
+    const int L = dyn_slice_rows(d);
+    int nslices = 0;
+    for (int e = 0; e < d.E_local; ++e) nslices += dyn_nslices(min(d.K, d.rows[e]), L);
+    const int per_xcd = (nslices * tiles_per_group + 7) >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int item = xcd * per_xcd + local;
+    if (local >= per_xcd || item >= nslices * tiles_per_group) return;
+    const int p = item / tiles_per_group, tile = item % tiles_per_group;
+    int e = 0, sl = p, ns = 1, rows_e = 0;
+    for (; e < d.E_local; ++e) {
+      rows_e = min(d.K, d.rows[e]);
+      ns = dyn_nslices(rows_e, L);
+      if (sl < ns) break;
+      sl -= ns;
+    }
+    z = e; zpart = p;
+    m0 = (tile % tiles_m) * BM; n0 = (tile / tiles_m) * BN; mext = d.Mext;
+    kchunk = ((rows_e + ns - 1) / ns + BKI - 1) / BKI * BKI;
+    kbase = sl * kchunk;
+    seg_hi = 1;
   } else {
-    const int ep = d.G / d.E_local;
-    z = (p % ep) * d.E_local + p / ep;
+    TileCoord tc;
+    if (!tile_of_block<BM, WGRAD, CMP>(d, bid, tc)) return;
+    z = tc.z; m0 = tc.m0; n0 = tc.n0; mext = tc.mext;
+    zpart = tc.split * d.E_local + z;  // split-K partials are indexed by (split, expert)
+    const int nsplit = WGRAD ? max(d.ksplit, 1) : 1;
+    if (WGRAD && nsplit > 1) {
+      if (nsplit <= nseg) {
+        seg_lo = tc.split * (nseg / nsplit);
+        seg_hi = seg_lo + nseg / nsplit;
+      } else {
+        const int rs = nsplit / nseg;  // row slices per segment
+        seg_lo = tc.split / rs;
+        seg_hi = seg_lo + 1;
+        kchunk = ((d.K + rs - 1) / rs + BKI - 1) / BKI * BKI;
+        kbase = (tc.split % rs) * kchunk;
+      }
+    }
   }
-  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
-  int mext = d.Mext;
-  if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
-  if (m0 >= mext) return;
 
   acc_tile_t<kM16> acc[NTM][NTN];
 #pragma unroll
@@ -775,22 +844,6 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
   const uint32_t vstride = h == 0 ? sub_dma_stride<B_COL>(d.ldb) : sub_dma_stride<A_COL>(d.lda);
   const int np = h == 0 ? NPB : NPA;  // pieces per wave of my operand's sub-tile
 
-  // K range of this block: all segments (groups that share the expert) and all their rows, or -- split-K --
-  // a run of whole segments (ksplit <= nseg) / one slice of one segment's rows (ksplit > nseg)
-  const int nseg = WGRAD ? d.G / d.E_local : 1;
-  int seg_lo = 0, seg_hi = nseg, kbase = 0, kchunk = d.K;
-  if (WGRAD && nsplit > 1) {
-    if (nsplit <= nseg) {
-      seg_lo = split * (nseg / nsplit);
-      seg_hi = seg_lo + nseg / nsplit;
-    } else {
-      const int rs = nsplit / nseg;  // row slices per segment
-      seg_lo = split / rs;
-      seg_hi = seg_lo + 1;
-      kchunk = ((d.K + rs - 1) / rs + BKI - 1) / BKI * BKI;
-      kbase = (split % rs) * kchunk;
-    }
-  }
   for (int seg = seg_lo; seg < seg_hi; ++seg) {
     const int g = WGRAD ? seg * d.E_local + z : z;
     const int e = WGRAD ? z : z % d.E_local;
@@ -944,13 +997,13 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
 #ifdef EVE_PP_STAMP
   { const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime(); stamp_v = lane == 60 ? c_ : stamp_v; }
 #endif
-  // split-K partials are indexed by (split, expert)
+  // (zpart: the group, or the (split, expert) / slice index of a split-K partial)
   if constexpr (kT)
-    tile_epilogue_t<EPI, WR>(acc, smem + wave_u * 4352, d, split * d.E_local + z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+    tile_epilogue_t<EPI, WR>(acc, smem + wave_u * 4352, d, zpart, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
   else
-    tile_epilogue<EPI, ACT, WR, kM16>(acc, smem, d, split * d.E_local + z, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
+    tile_epilogue<EPI, ACT, WR, kM16>(acc, smem, d, zpart, WGRAD ? z : z % d.E_local, m0, n0, mext, wave, lane);
   if constexpr (BIAS_GRAD) {
-    if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, split * d.E_local + z, m0);  // block-uniform
+    if (do_bias_grad) bias_grad_store<BM, 512>(bsum, smem, d, zpart, m0);  // block-uniform
   }
 #ifdef EVE_PP_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -960,33 +1013,23 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
+template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR, bool CMP = false>
 __global__ __launch_bounds__(512) void grouped_gemm_pp(MfmaPair pr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  pp_tile<A_COL, B_COL, EPI, ACT, WGRAD, BIAS_GRAD, BKI, WR>(pr, smem);
+  pp_tile<A_COL, B_COL, EPI, ACT, WGRAD, BIAS_GRAD, BKI, WR, CMP>(pr, smem);
 #endif
 }
 
-// Weight gradients.  The bias gradient (column sums of the k-major A tile) is taken by the tiles of the FIRST
-// column tile only; with 64-deep sub-tiles its accumulators do not fit next to 96 fragment and 128 accumulator
-// registers, so those tiles run the 32-deep body and all others the 64-deep one without bias sums (a K step of
-// 32 has half the MFMA work per barrier pair and reaches about half the MFMA rate).  Block-uniform branch.
+// Weight gradients: both GEMMs of a backward pass in one launch, every tile through the 64-deep body.  (The bias
+// gradients are formed outside these GEMMs -- bias_grads_kernel -- since round 2: the column sums of the k-major A
+// tile do not fit next to 96 fragment and 128 accumulator registers, and the 32-deep body that had room for them
+// reaches about half the MFMA rate.)
 template <int EPI>
 __global__ __launch_bounds__(512) void grouped_gemm_pp_wgrad(MfmaPair pr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bool second = blockIdx.x >= (unsigned)pr.n0;
-  const MfmaDesc& d = pr.d[second ? 1 : 0];
-  const unsigned bid = second ? blockIdx.x - (unsigned)pr.n0 : blockIdx.x;
-  const int tiles_m = (d.Mext + 255) / 256, tiles_per_group = tiles_m * (d.N / BN);
-  const int ngroups = d.E_local * max(d.ksplit, 1);
-  const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
-  const int local = bid >> 3, item = (bid & 7) * per_xcd + local;
-  if (local >= per_xcd || item >= ngroups * tiles_per_group) return;
-  const bool first_col_tile = !pr.nobias && (item % tiles_per_group) / tiles_m == 0;
-  if (first_col_tile) pp_tile<true, true, EPI, EVE_ACT_IDENTITY, true, true, 32, 4>(pr, smem);
-  else pp_tile<true, true, EPI, EVE_ACT_IDENTITY, true, false, 64, 4>(pr, smem);
+  pp_tile<true, true, EPI, EVE_ACT_IDENTITY, true, false, 64, 4>(pr, smem);
 #endif
 }
 
@@ -1082,7 +1125,7 @@ __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN],
   if constexpr (EPI == MEPI_DACT) colsum_store(cs, d, z, m0 / (WR * 32) + wm, ncol, lane);
 }
 
-template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR>
+template <bool A_COL, bool B_COL, int EPI, int ACT, bool WGRAD, bool BIAS_GRAD, int BKI, int WR, bool CMP = false>
 __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 64 * WR, KI = BKI / 16, NSLOT = 5;
@@ -1119,26 +1162,9 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
     const int which = gb >= (unsigned)pr.n0 ? 1 : 0;
     const MfmaDesc& d = pr.d[which];
     const unsigned bid = which ? gb - (unsigned)pr.n0 : gb;
-    const int tiles_m = (d.Mext + BM - 1) / BM, tiles_n = d.N / BN;
-    const int tiles_per_group = tiles_m * tiles_n;
-    const int ngroups = WGRAD ? d.E_local : d.G;
-    const int per_xcd = (ngroups * tiles_per_group + 7) >> 3;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int item = xcd * per_xcd + local;
-    if (local >= per_xcd || item >= ngroups * tiles_per_group) return false;
-    const int p = item / tiles_per_group;
-    const int tile = item % tiles_per_group;
-    int z;
-    if (WGRAD) {
-      z = p;
-    } else {
-      const int ep = d.G / d.E_local;
-      z = (p % ep) * d.E_local + p / ep;
-    }
-    const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
-    int mext = d.Mext;
-    if (!WGRAD && d.rows) mext = min(mext, d.rows[z]);
-    if (m0 >= mext) return false;
+    TileCoord tc;  // (persistent launches never split K: tc.split = 0)
+    if (!tile_of_block<BM, WGRAD, CMP>(d, bid, tc)) return false;
+    const int z = tc.z, m0 = tc.m0, n0 = tc.n0, mext = tc.mext;
     int kext = d.K;
     if (WGRAD && d.rows) kext = min(kext, d.rows[z]);  // single segment: group == expert
     T.which = which; T.z = z; T.m0 = m0; T.n0 = n0; T.mext = mext; T.kext = kext; T.nk = (kext + BKI - 1) / BKI;
@@ -1423,6 +1449,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *reinterpret_cast<uint4*>(out + i) = pack8(v);
 }
 
+// The same for dynamic slices (MfmaDesc::kslots): expert blockIdx.y's slices are part[first .. first + ns), slices
+// numbered expert-major as the GEMM numbered them (dyn_slice_rows / dyn_nslices on the same rows[]); blockIdx.z
+// picks the problem (dw2 / dw1: both have n elements per expert).
+__global__ __launch_bounds__(256) void wgrad_reduce_dyn_kernel(const float* __restrict__ part0, bf16_t* __restrict__ out0,
+                                                               const float* __restrict__ part1, bf16_t* __restrict__ out1,
+                                                               const int32_t* __restrict__ rows, int E_local, int K,
+                                                               int kslots, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  const int e = blockIdx.y;
+  int total = 0;
+  for (int q = 0; q < E_local; ++q) total += min(K, rows[q]);
+  const int L = max(64, ((total + kslots - 1) / kslots + 63) & ~63);
+  int first = 0;
+  for (int q = 0; q < e; ++q) first += dyn_nslices(min(K, rows[q]), L);
+  const int ns = dyn_nslices(min(K, rows[e]), L);
+  const float* part = (blockIdx.z ? part1 : part0) + (size_t)first * n + i;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = 0.f;
+  for (int j = 0; j < ns; ++j) {
+    const float4 a = *reinterpret_cast<const float4*>(part + (size_t)j * n);
+    const float4 b = *reinterpret_cast<const float4*>(part + (size_t)j * n + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  *reinterpret_cast<uint4*>((blockIdx.z ? out1 : out0) + (size_t)e * n + i) = pack8(v);
+}
+
 // Both bias gradients of the ping-pong path in ONE launch (they sit between the dz and the dx GEMM, where a launch
 // of a few microseconds is pure latency): blocks [0, nb2) form db2, the rest db1.
 //   db2: out2[e][c] = bf16(sum over the groups g that share expert e and rows r < rows[g] of dy[g][r][c]), dy a
@@ -1566,8 +1621,11 @@ static int cu_count() {  // of the current device; cached per device
 //   EVE_FFN_TILE_ROWS=128|192|256   force the block-tile height of the forward / dgrad launches
 //   EVE_FFN_KSPLIT=n           force the weight-gradient split-K factor
 //   EVE_FFN_WGRAD32=1          32-deep persistent weight-gradient kernel for all tiles
+//   EVE_FFN_WGRAD_PERSIST=1    persistent 64-deep kernel for the (unsplit) weight-gradient launch (measured in round 3:
+//                              eve_ffn_bwd 0.646 ms against 0.595 ms with one tile per workgroup -- it spills)
+//   EVE_FFN_COMPACT=0          few unequal groups: the plain G x ceil(R / BM) tile enumeration and equal K splits
 struct Knobs {
-  bool pingpong, persist, persist_act, wgrad32;
+  bool pingpong, persist, persist_act, wgrad32, wgrad_persist, compact;
   int tile_rows, ksplit;
 };
 static const Knobs& knobs() {
@@ -1579,12 +1637,14 @@ static const Knobs& knobs() {
     q.persist = !(env("EVE_FFN_PERSIST") && env("EVE_FFN_PERSIST")[0] == '0');
     q.persist_act = !(env("EVE_FFN_PERSIST_ACT") && env("EVE_FFN_PERSIST_ACT")[0] == '0');
     q.wgrad32 = env("EVE_FFN_WGRAD32") != nullptr;
+    q.wgrad_persist = env("EVE_FFN_WGRAD_PERSIST") && env("EVE_FFN_WGRAD_PERSIST")[0] == '1';
+    q.compact = !(env("EVE_FFN_COMPACT") && env("EVE_FFN_COMPACT")[0] == '0');
     q.tile_rows = env("EVE_FFN_TILE_ROWS") ? atoi(env("EVE_FFN_TILE_ROWS")) : 0;
     q.ksplit = env("EVE_FFN_KSPLIT") ? atoi(env("EVE_FFN_KSPLIT")) : 0;
     return q;
   }();
 #else
-  static const Knobs k = {true, true, true, false, 0, 0};
+  static const Knobs k = {true, true, true, false, false, true, 0, 0};
 #endif
   return k;
 }
@@ -1594,6 +1654,24 @@ static int g_stamp_grid = 0;
 static bool use_pingpong() { return knobs().pingpong; }
 // `shared` (EVE_FFN_SHARED_GPU of the call's flags): other kernels run beside this launch, so no persistent grid
 static bool use_persistent(bool shared) { return knobs().persist && !shared; }
+
+// Few groups whose heights differ (rows[] given, at most 8 groups, one segment per expert): the two-group modality
+// split of the non-MoE layers (12 608 vision rows beside 2 560 text rows at the cfg-2 shape).  Forward / dgrad tiles
+// are then enumerated over the rows that exist (MfmaDesc::compact) and the weight gradients' K ranges are cut into
+// equal slices of about (sum of rows) / kslots rows (MfmaDesc::kslots); with the plain enumeration the short
+// group's XCDs idle while the long group's run 5 rounds of tiles instead of 3, and equal splits of the padded K
+// range leave most of the short group's slices empty.
+static bool few_unequal_groups(const int32_t* rows, int G, int E_local) {
+  return knobs().compact && rows != nullptr && G == E_local && G >= 2 && G <= 8;
+}
+// slices aimed at: about two rounds of tiles for the CUs (both GEMMs share the launch)
+static int wgrad_dyn_slots(int E_local, int M, int I) {
+  const long tiles = 2L * (M / 256) * (I / 256);
+  long n = 2L * cu_count() / tiles - (E_local - 1);
+  if (n < E_local) n = E_local;
+  if (n > 16) n = 16;
+  return (int)n;
+}
 
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD, int BKI, int WR = 4>
 static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, const MfmaDesc* d2 = nullptr) {
@@ -1621,11 +1699,11 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, co
 #ifdef EVE_PP_STAMP
   if (persist && g_stamp_grid > 0) grid = dim3(g_stamp_grid);  // diagnostic: fewer CUs at work (tools/pp_stamps.hip)
 #endif
-#define EVE_PP_LAUNCH(A)                                                                                     \
+#define EVE_PP_LAUNCH_C(A, C)                                                                                \
   do {                                                                                                       \
-    auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                                \
+    auto kern = grouped_gemm_pp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR, C>;                         \
     static PerDeviceOnce once, oncep;                                                                        \
-    auto kernp = grouped_gemm_ppp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR>;                           \
+    auto kernp = grouped_gemm_ppp<A_COL, B_COL, EPI, A, WGRAD, BIAS_GRAD, BKI, WR, C>;                       \
     if (persist) {                                                                                           \
       if (int rc_ = reserve_lds(oncep, reinterpret_cast<const void*>(kernp), kLdsP)) return rc_;             \
     } else {                                                                                                 \
@@ -1633,6 +1711,14 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, co
     }                                                                                                        \
     if (persist) hipLaunchKernelGGL(kernp, grid, dim3(512), kLdsP, st, pr);                                  \
     else hipLaunchKernelGGL(kern, grid, dim3(512), kLds, st, pr);                                            \
+  } while (0)
+  // (the compact-enumeration variants exist for the forward / dgrad launches only)
+#define EVE_PP_LAUNCH(A)                                                                                     \
+  do {                                                                                                       \
+    if constexpr (!WGRAD) {                                                                                  \
+      if (d.compact) { EVE_PP_LAUNCH_C(A, true); break; }                                                    \
+    }                                                                                                        \
+    EVE_PP_LAUNCH_C(A, false);                                                                               \
   } while (0)
   if constexpr (EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT) {
     switch (act) {
@@ -1647,6 +1733,7 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, co
   } else {
     EVE_PP_LAUNCH(EVE_ACT_IDENTITY);
   }
+#undef EVE_PP_LAUNCH_C
 #undef EVE_PP_LAUNCH
   EVE_CHECK_LAUNCH("grouped_gemm_pp");
   return EVE_OK;
@@ -1677,7 +1764,7 @@ static TileChoice choose_tile(const MfmaDesc& d) {
 template <bool A_COL, bool B_COL, int EPI, bool WGRAD, bool BIAS_GRAD>
 static int launch(const MfmaDesc& d, int act, hipStream_t st, bool shared) {
   const TileChoice tc = choose_tile<A_COL, WGRAD>(d);
-  if (!tc.pingpong) {
+  if (!tc.pingpong) {  // (the lock-step kernels keep the plain tile enumeration: MfmaDesc::compact is not read there)
     if (tc.rows == 128) return launch_cfg<128, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
     return launch_cfg<256, 2, A_COL, B_COL, EPI, WGRAD, BIAS_GRAD>(d, act, st);
   }
@@ -1691,6 +1778,7 @@ int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, 
                  void* y, const int32_t* rows, int G, int E_local, int R, int M, int I, int act, bool shared, hipStream_t st) {
   MfmaDesc d{};
   d.G = G; d.E_local = E_local; d.rows = rows; d.Mext = R;
+  d.compact = few_unequal_groups(rows, G, E_local) && G == 2 ? 1 : 0;
   // z = x @ w1^T + b1 ; a = act(z)
   d.A = (const bf16_t*)x; d.a_g = (long)R * M; d.lda = M;
   d.B = (const bf16_t*)w1; d.b_g = (long)I * M; d.ldb = M;
@@ -1707,8 +1795,9 @@ int ffn_fwd_mfma(const void* x, const void* w1, const void* b1, const void* w2, 
 template <int EPI>
 static int launch_pp_wgrad(const MfmaDesc& d, const MfmaDesc& d2, hipStream_t st, bool nobias) {
   constexpr int kLds = 5 * 256 * 64 * 2;
-  auto blocks = [](const MfmaDesc& q) {
-    return 8 * ceil_div(q.E_local * (q.ksplit > 1 ? q.ksplit : 1) * (q.N / BN) * ceil_div(q.Mext, 256), 8);
+  auto blocks = [](const MfmaDesc& q) {  // (dynamic slices: at most kslots + E_local of them)
+    const int groups = q.kslots > 0 ? q.kslots + q.E_local : q.E_local * (q.ksplit > 1 ? q.ksplit : 1);
+    return 8 * ceil_div(groups * (q.N / BN) * ceil_div(q.Mext, 256), 8);
   };
   MfmaPair pr;
   pr.d[0] = d;
@@ -1753,8 +1842,12 @@ static size_t colsum_bytes(int G, int R, int I) { return align_up((size_t)G * (c
 size_t ffn_bwd_mfma_workspace_bytes(int G, int E_local, int R, int M, int I) {
   size_t n = use_pingpong() ? colsum_bytes(G, R, I) : 0;
   const int j = wgrad_ksplit(G, E_local, M, I);
-  if (j > 1) n += (size_t)j * E_local * (2 * (size_t)M * I) * sizeof(float);
-  return n;
+  size_t part = j > 1 ? (size_t)j * E_local * (2 * (size_t)M * I) * sizeof(float) : 0;
+  if (knobs().compact && G == E_local && G >= 2 && G <= 8) {  // rows[] may be given: room for the dynamic slices as well
+    const size_t dyn = (size_t)(wgrad_dyn_slots(E_local, M, I) + E_local) * (2 * (size_t)M * I) * sizeof(float);
+    if (dyn > part) part = dyn;
+  }
+  return n + part;
 }
 
 int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, const void* w1, const void* w2, void* dz,
@@ -1774,6 +1867,7 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   float* ksplit_ws = pp ? reinterpret_cast<float*>(static_cast<char*>(workspace) + colsum_bytes(G, R, I)) : nullptr;
   MfmaDesc d{};
   d.G = G; d.E_local = E_local; d.rows = rows;
+  d.compact = few_unequal_groups(rows, G, E_local) && G == 2 ? 1 : 0;
   // dz = (dy @ w2) * act'(z): A = dy [R,M] row-major, B = w2 [M,I] k-major
   d.Mext = R;
   d.A = (const bf16_t*)dy; d.a_g = (long)R * M; d.lda = M;
@@ -1814,7 +1908,21 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   d1.A = (const bf16_t*)dz; d1.a_g = (long)R * I; d1.lda = I;
   d1.B = (const bf16_t*)x; d1.b_g = (long)R * M; d1.ldb = M;
   d1.C = (bf16_t*)dw1; d1.c_g = (long)I * M; d1.ldc = M; d1.N = M; d1.K = R; d1.dbias = (bf16_t*)db1;
+  d.compact = d1.compact = 0;
   if (pp) {
+    if (few_unequal_groups(rows, G, E_local)) {  // dynamic slices, see few_unequal_groups
+      const int slots = wgrad_dyn_slots(E_local, M, I);
+      const size_t nw = (size_t)M * I;
+      float* p_dw2 = ksplit_ws;                               // [slots + E_local][M][I]
+      float* p_dw1 = p_dw2 + (size_t)(slots + E_local) * nw;  // [slots + E_local][I][M]
+      d.kslots = d1.kslots = slots;
+      d.Cpart = p_dw2; d1.Cpart = p_dw1;
+      if (int rc = launch_pp_wgrad<MEPI_STORE_F32>(d, d1, st, true)) return rc;
+      hipLaunchKernelGGL(wgrad_reduce_dyn_kernel, dim3((unsigned)((nw / 8 + 255) / 256), E_local, 2), dim3(256), 0, st,
+                         p_dw2, (bf16_t*)dw2, p_dw1, (bf16_t*)dw1, rows, E_local, R, slots, nw);
+      EVE_CHECK_LAUNCH("wgrad_reduce_dyn_kernel");
+      return EVE_OK;
+    }
     const int ks = wgrad_ksplit(G, E_local, M, I);
     if (ks > 1) {
       const size_t nw = (size_t)E_local * M * I;
@@ -1831,6 +1939,10 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
       EVE_CHECK_LAUNCH("wgrad_reduce_kernel");
       return EVE_OK;
     }
+#ifdef EVE_FFN_DEBUG_KNOBS
+    if (!knobs().wgrad32 && knobs().wgrad_persist && G == E_local)  // A/B only: slower than one tile per workgroup
+      return launch_pp<true, true, MEPI_STORE, true, false, 64>(d, act, st, shared, &d1);
+#endif
     if (!knobs().wgrad32) return launch_pp_wgrad<MEPI_STORE>(d, d1, st, true);  // one launch for both GEMMs
     return launch_pp<true, true, MEPI_STORE, true, true, 32>(d, act, st, shared, &d1);  // debug knob: all tiles 32 deep (persistent)
   }

@@ -147,13 +147,20 @@ def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
     (1, 1, 948, 768, 3072, False), (4, 1, 300, 768, 3072, True), (2, 2, 500, 768, 3072, True),
     (8, 2, 237, 768, 3072, True), (4, 4, 474, 768, 3072, True), (8, 4, 119, 768, 3072, True),
     # EVE-Large dims (M = 1024, I = 4096): every gradient against fp64
-    (4, 4, 300, 1024, 4096, True), (2, 1, 474, 1024, 4096, True), (4, 2, 256, 1024, 4096, False)])
+    (4, 4, 300, 1024, 4096, True), (2, 1, 474, 1024, 4096, True), (4, 2, 256, 1024, 4096, False),
+    # few groups, one segment per expert, ragged rows[] (the modality split's shape): compact tile enumeration in
+    # the forward / dgrad launches (two groups), weight gradients over dynamic K slices (round 3)
+    (2, 2, 1900, 768, 3072, True), (3, 3, 700, 768, 3072, True), (2, 2, 900, 1024, 4096, True)])
 def test_grouped_ffn_bf16_model_dims_and_split_k(G, E_l, R, M, I, use_rows):
     from eve_amd import _lib
-    want_split = {(768, 1): 4, (768, 2): 2, (768, 4): 1, (1024, 1): 2, (1024, 2): 1, (1024, 4): 1}[(M, E_l)]
+    want_split = {(768, 1): 4, (768, 2): 2, (768, 3): 2, (768, 4): 1, (1024, 1): 2, (1024, 2): 1, (1024, 4): 1}[(M, E_l)]
     nbytes = _lib.load().eve_ffn_bwd_workspace_bytes(G, E_l, R, M, I, _lib.BF16)
     colsum = -(-(G * (-(-R // 96) + 1) * I * 4) // 256) * 256   # fp32 partials of db1, one slot per wave row block
-    assert nbytes == colsum + (0 if want_split == 1 else want_split * E_l * 2 * M * I * 4)
+    part = 0 if want_split == 1 else want_split * E_l * 2 * M * I * 4
+    if G == E_l and 2 <= G <= 8:  # room for the dynamic slices: about two rounds of tiles, at most kslots + E_l slices
+        slots = min(16, max(E_l, 2 * 256 // (2 * (M // 256) * (I // 256)) - (E_l - 1)))
+        part = max(part, (slots + E_l) * 2 * M * I * 4)
+    assert nbytes == colsum + part
     test_grouped_ffn_fwd_bwd(torch.bfloat16, G, E_l, R, M, I, use_rows)
 
 

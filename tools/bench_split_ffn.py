@@ -66,9 +66,12 @@ class Wrap(torch.nn.Module):
 
 
 flops = 12.0 * M * I * B * T
-for name, fn in (("eve_amd eager", ours), ("stock torch ops (rocBLAS)", stock)):
+arms = (("eve_amd eager", ours),) if "--ours-only" in sys.argv else (("eve_amd eager", ours), ("stock torch ops (rocBLAS)", stock))
+for name, fn in arms:
     dt = timeit(fn)
     print(f"{name:28s} {dt*1e3:7.3f} ms/step  {B*T/dt/1e6:6.2f} M tokens/s  {flops/dt/1e12:6.0f} TFLOP/s")
+if "--ours-only" in sys.argv:
+    sys.exit(0)
 step = eve_amd.GraphedTrainStep(Wrap(m), h, dout, mode="vl", aux_weight=0.0)
 dt = timeit(lambda: step(h, dout))
 print(f"{'eve_amd HIP-graph replay':28s} {dt*1e3:7.3f} ms/step  {B*T/dt/1e6:6.2f} M tokens/s  {flops/dt/1e12:6.0f} TFLOP/s")
