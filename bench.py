@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3/4/5 and 12-layer encoder entries")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--allow-foreign-lib", action="store_true",
+                    help="run although EVE_MOE_LIB selects another library than eve_amd/libeve_moe.so (kernel A/B "
+                         "experiments); the line then names it.  Without the flag such a run is refused.")
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: after the timed region, check one expert-parallel step of every rank against the "
                          "single-rank layer (all experts local) on the same batch and noise; adds `verify` to the line")
@@ -214,6 +217,42 @@ def verify_against_single_rank(moe, h, dout, M, I, E, n_vis, dtype, dev, rank, w
             "max_abs_out_diff": -f[3], "max_abs_dh_diff": -f[4]}
 
 
+def hbm_rooflines(prof, steps, S, K, M, E, b):
+    """Gate / permute stages against the HBM roof: ALGORITHMIC bytes per call (`b` bytes per activation
+    element, K kept assignments) / the HIP-event time of the call on the launch stream / 8 TB/s.  A call is one to
+    three kernels and its event pair also spans their launch gaps, so these fractions are lower bounds on the
+    kernels' own (profiles/r03_kernel_roofline.txt has the rocprofv3 per-kernel durations and the PMC traffic)."""
+    alg = {
+        "eve_gate_logits_fwd": S * M * b + 4 * S * E,
+        "eve_gate_top2_fwd": (12 * E + 24) * S,
+        "eve_dispatch_fwd": (S + K) * M * b,
+        "eve_combine_fwd": (S + K) * M * b,
+        "eve_combine_bwd": (S + 2 * K) * M * b,
+        "eve_gate_top2_bwd": 12 * E * S,
+        "eve_route_bwd": (S + K) * M * b,
+        "eve_gate_wgrad": S * M * b + 4 * S * E,
+    }
+    out = {}
+    for name, nbytes in alg.items():
+        if name in prof and prof[name][1]:
+            us = prof[name][0] / prof[name][1] * 1e3
+            gbs = nbytes / (us * 1e-6) / 1e9
+            out[name] = {"us_per_call": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2),
+                         "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def gemm_frac(prof, steps, M, I, kept, peak=MFMA_BF16_PEAK_TFLOPS):
+    """Per-launch rate of the grouped expert GEMMs from a per-call profile: (TFLOP/s, fraction of the MFMA peak, ms)."""
+    ffn_ms = prof.get("eve_ffn_fwd", (0.0, 0))[0] + prof.get("eve_ffn_bwd", (0.0, 0))[0]
+    launches = 2 * prof.get("eve_ffn_fwd", (0.0, 0))[1] + 3 * prof.get("eve_ffn_bwd", (0.0, 0))[1]
+    if ffn_ms <= 0 or launches == 0:
+        return None
+    gemms = 2 * prof.get("eve_ffn_fwd", (0.0, 0))[1] + 4 * prof.get("eve_ffn_bwd", (0.0, 0))[1]
+    tflops = gemms * 2.0 * M * I * kept / (ffn_ms * 1e-3) / 1e12
+    return {"tflops": round(tflops, 1), "frac": round(tflops / peak, 4), "avg_launch_ms": round(ffn_ms / launches, 4)}
+
+
 def time_layer(moe, h, dout, steps, warmup, train=True):
     """ms per eager step of `moe` on (h, dout); train: fwd+bwd, else eval forward under no_grad."""
     params = list(moe.parameters())
@@ -259,9 +298,15 @@ def other_configs(dev, steps=10, warmup=4):
         ms = time_layer(moe, h, dout, steps, warmup, train)
         kept = int((moe.moe.last_slot >= 0).sum())
         flops = (12 if train else 4) * M * I * kept
+        from eve_amd import ops
+        ops.PROFILE.enable()  # the same steps once more, one C call per stage with HIP events around each
+        time_layer(moe, h, dout, 4, 0, train)
+        prof = ops.PROFILE.disable()
         out.append({"name": name, "workload": what, "tokens": B * T, "ms_per_step": round(ms, 4),
                     "tokens_per_s": round(B * T / ms * 1e3, 1), "kept_assignments": kept,
-                    "expert_gemm_tflops_over_whole_step": round(flops / ms / 1e9, 1), "launch": "eager", "steps": steps})
+                    "expert_gemm_tflops_over_whole_step": round(flops / ms / 1e9, 1),
+                    "expert_gemm_per_launch": gemm_frac(prof, 4, M, I, kept),
+                    "roofline_hbm": hbm_rooflines(prof, 4, B * T, kept, M, E, 2), "launch": "eager", "steps": steps})
         del h, dout
     del moe
     torch.cuda.empty_cache()
@@ -300,10 +345,53 @@ def encoder12(dev, steps=8, warmup=4):
     enqueue_ms = (time.perf_counter() - t0) / steps * 1e3  # host time to issue a step: close to ms_per_step = host-bound
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    # composition of the step: HIP events around every call into this library (one call per stage) over a few more
+    # steps; the remainder is stock PyTorch-ROCm (attention, norm1 / norm2_vl, the optimizer-free glue)
+    from eve_amd import ops
+    nprof = 3
+    ops.PROFILE.enable()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nprof):
+        step()
+    prof = ops.PROFILE.disable()
+    prof_ms = (time.perf_counter() - t0) / nprof * 1e3
+    lib_ms = sum(v[0] for v in prof.values()) / nprof
+    tagged = ops.PROFILE.tagged
+    split_ms = (tagged.get("eve_ffn_fwd[G=2]", (0.0, 0))[0] + tagged.get("eve_ffn_bwd[G=2]", (0.0, 0))[0]) / nprof
+    n_split = tagged.get("eve_ffn_fwd[G=2]", (0.0, 0))[1] // nprof
+    q = torch.randn(B, 12, T, 64, dtype=torch.bfloat16, device=dev, requires_grad=True)
+
+    def attn():
+        q.grad = None
+        torch.nn.functional.scaled_dot_product_attention(q, q, q).sum().backward()
+
+    for _ in range(3):
+        attn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        attn()
+    torch.cuda.synchronize()
+    attn_ms = (time.perf_counter() - t0) / 10 * 1e3 * 12
     res = {"workload": "EVE-Base encoder, 12 layers, B=64 x (197 + 40) tokens, bf16, fwd+bwd (BASELINE configs[1]); attention "
                        "is PyTorch-ROCm's fused SDPA, the FFN branches are this library", "ms_per_step": round(ms, 3),
            "tokens_per_s": round(B * T / ms * 1e3, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-           "launch": "eager", "host_enqueue_ms_per_step": round(enqueue_ms, 3), "steps": steps}
+           "launch": "eager", "host_enqueue_ms_per_step": round(enqueue_ms, 3), "steps": steps,
+           "composition": {
+               "ms_per_step_while_profiled": round(prof_ms, 3),
+               "library_calls_ms": round(lib_ms, 3), "library_share": round(lib_ms / prof_ms, 3),
+               "stock_fused_attention_ms_standalone": round(attn_ms, 3),
+               "stock_other_ms": round(max(prof_ms - lib_ms - attn_ms, 0.0), 3),
+               "split_ffn_layers": n_split,
+               "split_ffn_gemm_ms": round(split_ms, 3),
+               "split_ffn_gemm_tflops": round(n_split * 12.0 * M * 3072 * B * T / max(split_ms, 1e-9) / 1e9, 1),
+               "split_ffn_gemm_frac_of_mfma_peak": round(n_split * 12.0 * M * 3072 * B * T / max(split_ms, 1e-9) / 1e9
+                                                         / MFMA_BF16_PEAK_TFLOPS, 4),
+               "by_call_ms": {k: round(v[0] / nprof, 3) for k, v in sorted(prof.items())},
+               "note": "HIP events on the launch stream around each call of this library (eager issue); attention timed "
+                       "alone at the layer's shape (12 heads x 64) x 12 layers"}}
+    del q
     del enc, params
     torch.cuda.empty_cache()
     return res
@@ -316,7 +404,7 @@ def gemm_traffic(world, args, B):
     from eve_amd import _lib
     if not (world == 1 and args.dtype == "bf16" and args.model == "base" and B == 64):
         return None, None
-    for name in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -328,6 +416,10 @@ def gemm_traffic(world, args, B):
 
 def main():
     args = parse()
+    foreign = os.environ.get("EVE_MOE_LIB")
+    if foreign and not args.allow_foreign_lib:
+        raise SystemExit(f"bench.py: EVE_MOE_LIB={foreign} selects a library that is exempt from the source-digest check; "
+                         "unset it, or pass --allow-foreign-lib for an A/B experiment (the line then says so)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -455,8 +547,11 @@ def main():
                        "launch": "hipgraph replay of the whole step" if use_graph else "eager, one launch per kernel",
                        "library_source_hash": _lib.source_hash()},
             "roofline": roofline,
+            "roofline_hbm": hbm_rooflines(prof, args.steps, S, kept, M, E, 2 if args.dtype == "bf16" else 4),
             "phases_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }
+        if foreign:
+            line["foreign_library"] = foreign  # NOT the shipped library: an A/B experiment, not a result
         if verify is not None:
             line["verify"] = verify
         if rehearsal:

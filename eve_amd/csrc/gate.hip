@@ -658,8 +658,8 @@ __global__ __launch_bounds__(256) void gate_bwd32_kernel(const float* __restrict
 }
 
 // ================================================================ dwg = dlogits^T @ x
-// Stage 1: block b owns tokens [b*TS, (b+1)*TS); thread t owns 4 columns (granule t of the
-// M axis, looped when M/4 > blockDim) x all E experts.  Partials go to ws[b][E][M].
+// Stage 1: block (b, c) owns tokens [b*TS, (b+1)*TS) and experts [c*EMAX, (c+1)*EMAX); thread t owns 4 columns
+// (granule t of the M axis, looped when M/4 > blockDim) x those experts.  Partials go to ws[b][E][M].
 // Stage 2: sum partials over blocks in fixed order.
 template <typename T, int EMAX>
 __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const T* __restrict__ h, const T* __restrict__ vemb,
@@ -671,8 +671,9 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const T* __rest
   float* dl = reinterpret_cast<float*>(smem);  // [TS][EMAX]
   const int s_begin = blockIdx.x * TS;
   const int s_end = min(S, s_begin + TS);
+  const int e0 = blockIdx.y * EMAX;
   for (int i = threadIdx.x; i < TS * EMAX; i += blockDim.x) {
-    const int t = i / EMAX, e = i % EMAX;
+    const int t = i / EMAX, e = e0 + i % EMAX;
     const int s = s_begin + t;
     dl[i] = (s < s_end && e < E) ? dlogits[(size_t)s * E + e] : 0.f;
   }
@@ -706,7 +707,8 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const T* __rest
     float* out = part + (size_t)blockIdx.x * E * M;
 #pragma unroll
     for (int e = 0; e < EMAX; ++e)
-      if (e < E) *reinterpret_cast<float4*>(out + (size_t)e * M + gr * 4) = make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
+      if (e0 + e < E)
+        *reinterpret_cast<float4*>(out + (size_t)(e0 + e) * M + gr * 4) = make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
   }
 }
 
@@ -835,6 +837,99 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
   }
 }
 
+// bf16 activations, round 3: the same arithmetic per logit as gate_logits_mfma_kernel's bf16 branch (bf16 x, wg as
+// its exact three-way bf16 split, products of an fp32 FMA), but a workgroup WALKS token tiles.  One 512-thread
+// workgroup per CU; its 8 waves split the K axis (KB 16-wide k blocks each) and keep their slice of wg -- split once
+// per workgroup, not once per 32 tokens: the split is ~10 VALU instructions per element and was redone by every one
+// of the S / 32 blocks -- in registers across the tiles; the rows of the next tile are in flight while the current
+// one is multiplied, reduced over the waves through LDS in wave order (deterministic) and stored.
+template <bool EMB, int KB>
+__global__ __launch_bounds__(512) void gate_logits_walk_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ vemb,
+                                                               const bf16_t* __restrict__ temb,
+                                                               const float* __restrict__ wg, float* __restrict__ logits,
+                                                               int S, int T_, int n_vis, int mode, int M, int E,
+                                                               int ntiles, int tiles_per_block) {
+  __shared__ float red[8][16][64];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 31, hh = lane >> 5;
+  const int k_lo = wave * KB * 16;
+  const int t_begin = blockIdx.x * tiles_per_block, t_end = min(ntiles, t_begin + tiles_per_block);
+  if (t_begin >= t_end) return;
+  // per-lane k offsets of the KB blocks (clamped: blocks past M are masked through wg)
+  int kof[KB];
+#pragma unroll
+  for (int u = 0; u < KB; ++u) kof[u] = min(k_lo + 16 * u, M - 16) + 8 * hh;
+  Vec16<bf16_t> xa0[KB], xa1[KB];  // (two named buffers: a dynamically indexed array would live in scratch memory)
+  auto load_tile = [&](int t, Vec16<bf16_t> (&dst)[KB]) {
+    const int s = min(t * 32 + i, S - 1);
+    const bf16_t* hp = h + (size_t)s * M;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) dst[u] = load16<bf16_t>(hp + kof[u]);
+  };
+  load_tile(t_begin, xa0);
+  if (t_begin + 1 < t_end) load_tile(t_begin + 1, xa1);
+  // my slice of wg (expert i), split once
+  gate_bf16x8 bh[KB], bm[KB], bl[KB];
+  {
+    const float* wp = wg + (size_t)min(i, E - 1) * M;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const float m = (i < E && k_lo + 16 * u < M) ? 1.f : 0.f;
+      const float4 w0 = *reinterpret_cast<const float4*>(wp + kof[u]), w1 = *reinterpret_cast<const float4*>(wp + kof[u] + 4);
+      const float b[8] = {w0.x * m, w0.y * m, w0.z * m, w0.w * m, w1.x * m, w1.y * m, w1.z * m, w1.w * m};
+      split3_bf16(b, bh[u], bm[u], bl[u]);
+    }
+  }
+  auto tile = [&](int t, Vec16<bf16_t> (&x)[KB]) {
+    if constexpr (EMB) {
+      const int s = min(t * 32 + i, S - 1);
+      const bf16_t* emb = token_modality(s, T_, n_vis, mode) ? temb : vemb;
+      Vec16<bf16_t> ev[KB];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) ev[u] = load16<bf16_t>(emb + kof[u]);
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = x[u].get(j) + ev[u].get(j);
+        x[u].set_all(xs);
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const gate_bf16x8 av = __builtin_bit_cast(gate_bf16x8, x[u].raw);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bl[u], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm[u], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh[u], acc, 0, 0, 0);
+    }
+    if (t + 2 < t_end) load_tile(t + 2, x);  // the buffer just consumed takes the tile after next
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // D: column (expert) = lane & 31, row (token) = (r & 3) + 8 * (r >> 2) + 4 * hh; wave w finishes registers 2w, 2w+1
+    if (i < E) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = wave * 2 + q;
+        float v = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v += red[w][r][lane];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (t * 32 + row < S) logits[(size_t)(t * 32 + row) * E + i] = v;
+      }
+    }
+    __syncthreads();
+  };
+  for (int t = t_begin; t < t_end; t += 2) {
+    tile(t, xa0);
+    if (t + 1 < t_end) tile(t + 1, xa1);
+  }
+}
+
 // dwg partials: D[32 experts x 32 "virtual" cols] += A[32 experts x 2 tokens] * B[2 tokens x 32 cols].
 // Block (x = token chunk of TS tokens, y = group of 256 columns); its 4 waves split the chunk's tokens
 // and are summed through LDS in a fixed order (deterministic).  Lane i loads the 8 contiguous elements
@@ -960,10 +1055,40 @@ __global__ __launch_bounds__(256) void sum_partials4_kernel(const float* __restr
 
 // =================================================================== host launchers
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static int gate_cu_count() {  // of the current device
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+    n = 256;
+  return n;
+}
 
 template <typename T>
 static int launch_logits(const void* h, const void* ve, const void* te, const float* wg, float* logits, int S, int T_,
                          int n_vis, int mode, int M, int E, hipStream_t st) {
+  if constexpr (Vec16<T>::N == 8) {
+    // bf16: the tile-walking kernel (one workgroup per CU, wg split once per workgroup); K slices of up to 8 blocks
+    const int kb = ceil_div(M / 16, 8);
+    if (E <= 32 && M % 16 == 0 && kb <= 8) {
+      const int ntiles = ceil_div(S, 32);
+      const int tpb = ceil_div(ntiles, gate_cu_count());
+      const dim3 grid(ceil_div(ntiles, tpb));
+#define EVE_WALK(KB_)                                                                                                   \
+  case KB_:                                                                                                             \
+    if (mode != EVE_MODE_NONE)                                                                                          \
+      hipLaunchKernelGGL((gate_logits_walk_kernel<true, KB_>), grid, dim3(512), 0, st, (const bf16_t*)h,               \
+                         (const bf16_t*)ve, (const bf16_t*)te, wg, logits, S, T_, n_vis, mode, M, E, ntiles, tpb);      \
+    else                                                                                                                \
+      hipLaunchKernelGGL((gate_logits_walk_kernel<false, KB_>), grid, dim3(512), 0, st, (const bf16_t*)h,              \
+                         (const bf16_t*)ve, (const bf16_t*)te, wg, logits, S, T_, n_vis, mode, M, E, ntiles, tpb);      \
+    break;
+      switch (kb) {
+        EVE_WALK(1) EVE_WALK(2) EVE_WALK(3) EVE_WALK(4) EVE_WALK(5) EVE_WALK(6) EVE_WALK(7) EVE_WALK(8)
+      }
+#undef EVE_WALK
+      EVE_CHECK_LAUNCH("gate_logits_walk_kernel");
+      return EVE_OK;
+    }
+  }
   if (E <= 32 && M % 16 == 0) {
     if (mode != EVE_MODE_NONE)
       hipLaunchKernelGGL((gate_logits_mfma_kernel<T, true>), dim3(ceil_div(S, 32)), dim3(256), 0, st, (const T*)h,
@@ -1213,7 +1338,6 @@ extern "C" int eve_gate_wgrad(const void* h, const void* vision_embed, const voi
                               size_t workspace_bytes, void* stream) {
   EVE_REQUIRE(h && dlogits && dwg && workspace, EVE_ERR_ARG, "eve_gate_wgrad: null pointer");
   EVE_REQUIRE(S > 0 && E > 0 && M % 8 == 0, EVE_ERR_ARG, "eve_gate_wgrad: bad shape");
-  EVE_REQUIRE(E <= 32, EVE_ERR_UNSUPPORTED, "eve_gate_wgrad: E=%d > 32 not supported", E);
   if (mode != EVE_MODE_NONE) EVE_REQUIRE(vision_embed && text_embed && T > 0, EVE_ERR_ARG, "eve_gate_wgrad: embeddings required");
   const size_t need = eve_gate_wgrad_workspace_bytes(S, M, E);
   EVE_REQUIRE(workspace_bytes >= need, EVE_ERR_WORKSPACE, "eve_gate_wgrad: workspace %zu < %zu", workspace_bytes, need);
@@ -1242,14 +1366,15 @@ extern "C" int eve_gate_wgrad(const void* h, const void* vision_embed, const voi
     EVE_CHECK_LAUNCH("sum_partials4_kernel");
     return EVE_OK;
   }
-  const int nb = ceil_div(S, kWgradTS);
+  const int nb = ceil_div(S, kWgradTS);  // more than 32 experts (or M % 8 != 0): VALU kernel, 32 experts per block
   const size_t lds = (size_t)kWgradTS * 32 * 4;
+  const dim3 vgrid(nb, ceil_div(E, 32));
   if (dtype == EVE_F32)
-    hipLaunchKernelGGL((gate_wgrad_partial_kernel<float, 32>), dim3(nb), dim3(256), lds, st, (const float*)h,
+    hipLaunchKernelGGL((gate_wgrad_partial_kernel<float, 32>), vgrid, dim3(256), lds, st, (const float*)h,
                        (const float*)vision_embed, (const float*)text_embed, dlogits, part, S, T, n_vis, mode, M, E,
                        kWgradTS);
   else if (dtype == EVE_BF16)
-    hipLaunchKernelGGL((gate_wgrad_partial_kernel<bf16_t, 32>), dim3(nb), dim3(256), lds, st, (const bf16_t*)h,
+    hipLaunchKernelGGL((gate_wgrad_partial_kernel<bf16_t, 32>), vgrid, dim3(256), lds, st, (const bf16_t*)h,
                        (const bf16_t*)vision_embed, (const bf16_t*)text_embed, dlogits, part, S, T, n_vis, mode, M, E,
                        kWgradTS);
   else {

@@ -52,8 +52,9 @@ class MoE(torch.nn.Module):
                         noisy_gate_policy, drop_tokens, use_rts)
         self.moe = MOELayer(gate, experts, self.expert_group_name, self.ep_size, self.num_local_experts,
                             num_tokens=num_tokens)
-        if self.use_residual:
-            # Residual-MoE branch (reference layer.py:72-75, :94-101); unused by EVE
+        if use_residual:
+            # Residual-MoE (reference layer.py:72-75): a dense copy of the expert beside the routed ones and a
+            # two-way mixing head; EVE never enables it, so it runs as plain torch glue around the HIP layer
             self.mlp = expert
             self.coefficient = torch.nn.Linear(hidden_size, 2)
 
@@ -64,11 +65,13 @@ class MoE(torch.nn.Module):
 
     def forward(self, hidden_states, **kwargs):
         """-> (output, l_aux, exp_counts); `mode='vl'|'vision'|'text'` selects the modality routing."""
-        output = self.moe(hidden_states, **kwargs)
-        if self.use_residual:
-            output_mlp = self.mlp(hidden_states)
-            if type(output_mlp) is tuple:
-                output_mlp = output_mlp[0]
-            coef = torch.nn.functional.softmax(self.coefficient(hidden_states), dim=-1)
-            output = output * coef[..., 0:1] + output_mlp * coef[..., 1:]
-        return output, self.moe.l_aux, self.moe.exp_counts
+        routed = self.moe(hidden_states, **kwargs)
+        if not self.use_residual:
+            return routed, self.moe.l_aux, self.moe.exp_counts
+        # Residual-MoE (reference layer.py:94-101): softmax-weighted blend of the routed and the dense branch
+        dense = self.mlp(hidden_states)
+        dense = dense[0] if isinstance(dense, tuple) else dense
+        mix = torch.softmax(self.coefficient(hidden_states), dim=-1)
+        w_routed, w_dense = mix.unbind(dim=-1)
+        blended = routed * w_routed.unsqueeze(-1) + dense * w_dense.unsqueeze(-1)
+        return blended, self.moe.l_aux, self.moe.exp_counts

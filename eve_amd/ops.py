@@ -53,28 +53,37 @@ class _Profile:
     def __init__(self):
         self.on = False
         self._ev = []
+        self.tagged = {}
 
     def enable(self):
         self.on, self._ev = True, []
 
     def disable(self):
+        """-> {entry point: (total ms, calls)}; `self.tagged` then holds the same split by the calls' tags
+        ({"eve_ffn_fwd[G=2]": ...}: the grouped GEMMs of a 2-group modality split beside those of a 32-expert layer)."""
         self.on = False
         torch.cuda.synchronize()
-        out = {}
-        for name, a, b in self._ev:
+        out, tagged = {}, {}
+        for name, tag, a, b in self._ev:
+            dt = a.elapsed_time(b)
             ms, n = out.get(name, (0.0, 0))
-            out[name] = (ms + a.elapsed_time(b), n + 1)
+            out[name] = (ms + dt, n + 1)
+            if tag is not None:
+                key = f"{name}[{tag}]"
+                ms, n = tagged.get(key, (0.0, 0))
+                tagged[key] = (ms + dt, n + 1)
         self._ev = []
+        self.tagged = tagged
         return out
 
-    def call(self, name, *args):
+    def call(self, name, *args, tag=None):
         if not self.on:
             return _lib.call(name, *args)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _lib.call(name, *args)
         b.record()
-        self._ev.append((name, a, b))
+        self._ev.append((name, tag, a, b))
 
 
 PROFILE = _Profile()
@@ -259,7 +268,7 @@ def ffn_fwd(x, w1, b1, w2, b2, rows, act: int, save_z: bool = True, shared_gpu: 
     a = torch.empty(G, R, I, dtype=x.dtype, device=x.device)
     y = torch.empty(G, R, M, dtype=x.dtype, device=x.device)
     PROFILE.call("eve_ffn_fwd", _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(z), _p(a), _p(y), _p(rows), G, E_l, R, M, I,
-              act, _dt(x), _lib.FFN_SHARED_GPU if shared_gpu else 0, _stream())
+              act, _dt(x), _lib.FFN_SHARED_GPU if shared_gpu else 0, _stream(), tag=f"G={G}")
     return z, a, y
 
 
@@ -286,7 +295,8 @@ def ffn_bwd(dy, x, z, a, w1, w2, rows, act: int, grads_out=None, shared_gpu: boo
     nbytes = _lib.load().eve_ffn_bwd_workspace_bytes(G, E_l, R, M, I, _dt(x))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     PROFILE.call("eve_ffn_bwd", _p(dy), _p(x), _p(z), _p(a), _p(w1), _p(w2), _p(dz), _p(dx), _p(dw1), _p(db1), _p(dw2),
-              _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _lib.FFN_SHARED_GPU if shared_gpu else 0, _p(ws), nbytes, _stream())
+              _p(db2), _p(rows), G, E_l, R, M, I, act, _dt(x), _lib.FFN_SHARED_GPU if shared_gpu else 0, _p(ws), nbytes, _stream(),
+              tag=f"G={G}")
     return dx, dw1, db1, dw2, db2
 
 

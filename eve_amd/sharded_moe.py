@@ -384,32 +384,16 @@ class _CombineFn(torch.autograd.Function):
         return dy, dw, None, None, None
 
 
-_cast_cache: Dict[int, tuple] = {}
-
-
-def _cast_cached(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
-    """`t.to(dtype).contiguous()` for a (small) parameter, re-made only when the parameter has changed: fp32 master
-    parameters with bf16 activations would otherwise pay a cast kernel per parameter and step.  Keyed by the tensor
-    object and its version counter (optimizers update in place and bump it; `.data` swaps change the storage pointer).
-    Never cached under graph capture: the cast must be a node of the graph so that replays see updated parameters."""
+def _cast(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
+    """`t.to(dtype).contiguous()` of a (small) parameter, made anew on every call like the per-stage path makes it.
+    Round 2 kept the copy per (tensor, version counter, storage pointer); an update through `.data` -- what older
+    `transformers.AdamW` builds and fairscale's OSS do -- changes neither, so the fused path would have gone on using
+    stale values.  The cast is a [M]-sized kernel and only exists when parameter and activation dtypes differ."""
     if t is None:
         return None
     if t.dtype == dtype:
         return t if t.is_contiguous() else t.contiguous()
-    if torch.cuda.is_current_stream_capturing():
-        return t.to(dtype).contiguous()
-    import weakref
-    key = id(t)
-    hit = _cast_cache.get(key)
-    if hit is not None:
-        ref, version, ptr, dt, out = hit
-        if ref() is t and version == t._version and ptr == t.data_ptr() and dt == dtype:
-            return out
-    out = t.detach().to(dtype).contiguous()
-    if len(_cast_cache) > 256:
-        _cast_cache.clear()
-    _cast_cache[key] = (weakref.ref(t), t._version, t.data_ptr(), dtype, out)
-    return out
+    return t.detach().to(dtype).contiguous()
 
 
 _fused_plans: Dict[tuple, tuple] = {}
@@ -447,9 +431,9 @@ class _FusedMoEFn(torch.autograd.Function):
         B, T, M = h.shape
         S = B * T
         h2d = h.contiguous().view(S, M)
-        wg32 = _cast_cached(wg, torch.float32)
-        ve = _cast_cached(vemb, h.dtype)
-        te = _cast_cached(temb, h.dtype)
+        wg32 = _cast(wg, torch.float32)
+        ve = _cast(vemb, h.dtype)
+        te = _cast(temb, h.dtype)
         noise = noise.contiguous()
         E, I = wg32.shape[0], w1.shape[1]
         for t, n in ((w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (ve, "vision_embed"), (te, "text_embed")):
@@ -614,21 +598,14 @@ class _LogitsFn(torch.autograd.Function):
         return dx, dwg
 
 
-uniform_map: Dict[torch.device, Callable] = {}
-
-
 def multiplicative_jitter(x: Tensor, device: torch.device, epsilon: float = 1e-2) -> Tensor:
-    """x * U(1-eps, 1+eps) (reference sharded_moe.py:46-67; only with noisy_gate_policy='Jitter',
-    which EVE never sets)."""
+    """Scales every element of `x` by an independent draw from U[1 - epsilon, 1 + epsilon) (what the reference's
+    gate applies to its input under noisy_gate_policy='Jitter', sharded_moe.py:46-67; EVE never sets that policy).
+    One `torch.rand` draw of x's shape from the global generator of `device`."""
     if epsilon == 0:
         return x
-    device = torch.device(device)
-    uniform = uniform_map.get(device)
-    if uniform is None:
-        uniform = torch.distributions.uniform.Uniform(low=torch.tensor(1.0 - epsilon, device=device),
-                                                      high=torch.tensor(1.0 + epsilon, device=device)).rsample
-        uniform_map[device] = uniform
-    return x * uniform(x.shape)
+    u = torch.rand(x.shape, dtype=x.dtype if x.is_floating_point() else torch.float32, device=torch.device(device))
+    return x * (u * (2.0 * epsilon) + (1.0 - epsilon))
 
 
 class MOELayer(nn.Module):
@@ -746,7 +723,9 @@ class MOELayer(nn.Module):
                 gate.min_capacity, is_uniform, self.experts._act_code, torch.is_grad_enabled())
             self.l_aux = l_aux
             self.exp_counts = self._host_counts(exp_counts)
-            self.last_slot = slot
+            # a copy (S * 8 bytes): a view would keep the whole `saved` blob (xd, z, a, y: ~0.5 GB at the cfg-2 shape)
+            # alive on the module after backward, until this layer's next forward
+            self.last_slot = slot.clone()
             return out.view(orig_shape)
 
         xd, weight, l_aux, slot, slot_token, slot_weight, rows, exp_counts = _RouteDispatchFn.apply(

@@ -50,17 +50,46 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
 
 
+WORST = {}  # name -> largest err / (atol + rtol * |ref|) seen by the scaled checks of this process (1.0 = at the bar)
+
+
 def assert_close_scaled(got, ref, rtol, atol_frac, name=""):
     """Per-element |got - ref| <= atol + rtol * |ref| with atol = atol_frac * rms(ref): the tolerance the
     BASELINE states (rtol 2e-2 for bf16, 1e-5 for fp32) on every element, plus an absolute floor tied to the
-    tensor's own scale for the elements near zero (a norm-wise bound alone leaves small elements unchecked)."""
+    tensor's own scale for the elements near zero (a norm-wise bound alone leaves small elements unchecked).
+    Returns the measured worst case as a fraction of the bound (also kept in WORST[name] and named in the
+    failure message), so that a test can report how much of the floor it uses."""
     got, ref = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(ref).detach().double().cpu()
     assert got.shape == ref.shape, (name, tuple(got.shape), tuple(ref.shape))
     rms = float(ref.pow(2).mean().sqrt())
     atol = atol_frac * max(rms, 1e-30)
     err = (got - ref).abs()
-    bad = err > atol + rtol * ref.abs()
+    bound = atol + rtol * ref.abs()
+    used = float((err / bound).max()) if err.numel() else 0.0
+    WORST[name] = max(WORST.get(name, 0.0), used)
+    bad = err > bound
     if bool(bad.any()):
         i = int(torch.argmax(err - rtol * ref.abs()))
         raise AssertionError(f"{name}: {int(bad.sum())} of {bad.numel()} elements outside rtol {rtol} + atol {atol:.3g} "
-                             f"(rms {rms:.3g}); worst: got {float(got.flatten()[i]):.6g} ref {float(ref.flatten()[i]):.6g}")
+                             f"(rms {rms:.3g}); worst: got {float(got.flatten()[i]):.6g} ref {float(ref.flatten()[i]):.6g}; "
+                             f"measured worst case = {used:.2f} x the bound, largest |err| = {float(err.max()):.3g} "
+                             f"= {float(err.max()) / max(rms, 1e-30):.3g} x rms")
+    return used
+
+
+def assert_fp32_close(got, ref, name="", rtol=1e-5, floor=1e-5):
+    """The fp32 contract of BASELINE.json (1e-5) on every element: |got - ref| <= rtol * |ref| + floor * max|ref|.
+    The floor is tied to the tensor's largest element: a K-term fp32 dot product summed in another order than the
+    reference's CPU GEMM differs by about that much wherever its terms cancel."""
+    got, ref = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(ref).detach().double().cpu()
+    assert got.shape == ref.shape, (name, tuple(got.shape), tuple(ref.shape))
+    scale = float(ref.abs().max()) if ref.numel() else 0.0
+    err = (got - ref).abs()
+    bound = rtol * ref.abs() + floor * max(scale, 1e-30)
+    used = float((err / bound).max()) if err.numel() else 0.0
+    WORST[name] = max(WORST.get(name, 0.0), used)
+    if used > 1.0:
+        i = int(torch.argmax(err / bound))
+        raise AssertionError(f"{name}: fp32 bar (rtol {rtol} + {floor} x max|ref| = {floor * scale:.3g}) exceeded "
+                             f"{used:.2f}-fold; worst: got {float(got.flatten()[i]):.8g} ref {float(ref.flatten()[i]):.8g}")
+    return used

@@ -112,10 +112,11 @@ def test_fused_entry_points_reject_small_buffers_and_bad_shapes():
     assert lib.eve_moe_workspace_bytes(ref, 7) == 0
 
 
-def test_cached_parameter_casts_follow_in_place_updates():
-    """fp32 modality embeddings with bf16 activations: the fused path keeps a cast copy per parameter version; an
-    optimizer-style in-place update must be seen by the next forward (same results as the per-stage path, which casts
-    every call)."""
+def test_parameter_casts_follow_in_place_updates():
+    """fp32 modality embeddings with bf16 activations: the fused path casts them per call; an optimizer-style in-place
+    update -- through the parameter (bumps its version counter) or through `.data` (bumps nothing and keeps the storage
+    pointer: older transformers.AdamW, fairscale OSS) -- must be seen by the next forward: same results as the
+    per-stage path."""
     M, I, E, B, T, n_vis = 64, 128, 8, 4, 11, 6
     p = orc.make_params(M, I, E, seed=5)
     moe = build_moe(p, M, I, E, n_vis, device=DEV)
@@ -124,14 +125,21 @@ def test_cached_parameter_casts_follow_in_place_updates():
     h = torch.randn(B, T, M, generator=g).to(torch.bfloat16).to(DEV)
     dout = torch.randn(B, T, M, generator=g).to(torch.bfloat16).to(DEV)
     noise = orc.gumbel_noise((B * T, E), generator=g).to(DEV)
-    for step in range(3):
+    for step in range(5):
         a = _run(moe, h, dout, noise, "vl", fused=True)
         b = _run(moe, h, dout, noise, "vl", fused=False)
         for i, (x, y) in enumerate(zip(a, b)):
             assert (x is None) == (y is None), (step, i)
             if x is not None:
                 assert x.dtype == y.dtype and torch.equal(x, y), f"step {step}: result {i} differs"
-        with torch.no_grad():  # what an optimizer does: in place, bumps the version counter
-            moe.moe.vision_embed.add_(0.05)
-            moe.moe.text_embed.mul_(1.5)
-            moe.moe.gate.wg.weight.add_(0.01 * torch.randn_like(moe.moe.gate.wg.weight))
+        if step % 2 == 0:
+            with torch.no_grad():  # in place on the parameter: bumps the version counter
+                moe.moe.vision_embed.add_(0.05)
+                moe.moe.text_embed.mul_(1.5)
+                moe.moe.gate.wg.weight.add_(0.01 * torch.randn_like(moe.moe.gate.wg.weight))
+        else:  # through .data: no version bump, same storage
+            ver = moe.moe.vision_embed._version
+            moe.moe.vision_embed.data.add_(-0.03)
+            moe.moe.text_embed.data.mul_(0.7)
+            moe.moe.gate.wg.weight.data.add_(0.01)
+            assert moe.moe.vision_embed._version == ver

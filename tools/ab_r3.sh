@@ -14,7 +14,7 @@ for c in 0 1; do
 done
 for p in 0 1; do
   echo "== MoE bench, EVE_FFN_WGRAD_PERSIST=$p"
-  EVE_FFN_WGRAD_PERSIST=$p timeout -k 10 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $out/bench_wp$p.json 2> $out/bench_wp$p.err || { tail -5 $out/bench_wp$p.err; exit 3; }
+  EVE_FFN_WGRAD_PERSIST=$p timeout -k 10 200 python bench.py --allow-foreign-lib --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs > $out/bench_wp$p.json 2> $out/bench_wp$p.err || { tail -5 $out/bench_wp$p.err; exit 3; }
   python - <<PY
 import json
 l=json.load(open("$out/bench_wp$p.json"))
