@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("EVE_MOE_LIB", LIB_PATH)  # A/B experiments: an altern
 F32, BF16 = 0, 1
 MODE_NONE, MODE_VL, MODE_VISION, MODE_TEXT = 0, 1, 2, 3
 ACT_QUICK_GELU, ACT_GELU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 FFN_SHARED_GPU = 1
 
 _P, _I, _Z = c_void_p, c_int, c_size_t
@@ -58,8 +58,13 @@ SIGNATURES = {
     "eve_moe_saved_offsets": (c_int, [_P, _I, _P, _I]),
     "eve_moe_fwd": (c_int, [_P] * 6 + [_I] + [_P] * 7 + [_Z, _I, _P, _Z, _P]),
     "eve_moe_bwd": (c_int, [_P] * 10 + [_Z] + [_P] * 9 + [_Z, _P]),
+    "eve_moe_route_fwd": (c_int, [_P] * 6 + [_I] + [_P] * 3 + [_Z, _P, _Z, _P]),
+    "eve_moe_finish_fwd": (c_int, [_P, _P, _P, _Z, _P, _P]),
+    "eve_moe_finish_bwd": (c_int, [_P, _P, _P, _P, _Z, _P, _P, _P]),
+    "eve_moe_route_bwd": (c_int, [_P] * 9 + [_Z] + [_P] * 5 + [_Z, _P]),
 }
 MOE_PASS_INFERENCE, MOE_PASS_FORWARD, MOE_PASS_BACKWARD = 0, 1, 2
+MOE_PASS_ROUTE_FWD, MOE_PASS_ROUTE_BWD = 3, 4
 MOE_SAVED_FIELDS = ("gates", "idx", "loc", "slot", "weight", "slot_token", "slot_weight", "rows", "exp_counts",
                     "xd", "z", "a", "y")
 

@@ -84,6 +84,28 @@ static Layout bwd_ws_layout(const eve_moe_shape& p) {
   return L;
 }
 
+// expert-parallel halves: scratch of eve_moe_route_fwd (logits, gate scratch) and of eve_moe_route_bwd (dlogits and
+// the partials of the closing reductions)
+static Layout route_fwd_ws_layout(const eve_moe_shape& p) {
+  Layout L{};
+  size_t o = 0;
+  auto put = [&](int f, size_t bytes) { L.off[f] = o; o = align_up(o + bytes, 256); };
+  put(WS_LOGITS, (size_t)p.S * p.E * 4);
+  put(WS_GATE, eve_gate_workspace_bytes(p.S, p.E));
+  L.total = o;
+  return L;
+}
+static Layout route_bwd_ws_layout(const eve_moe_shape& p) {
+  Layout L{};
+  size_t o = 0;
+  auto put = [&](int f, size_t bytes) { L.off[f] = o; o = align_up(o + bytes, 256); };
+  put(WS_DLOGITS, (size_t)p.S * p.E * 4);
+  put(WS_WGRAD, eve_gate_wgrad_workspace_bytes(p.S, p.M, p.E));
+  put(WS_EMBED, eve_embed_grad_workspace_bytes(p.S, p.M));
+  L.total = o;
+  return L;
+}
+
 static int check_shape(const char* who, const eve_moe_shape* p) {
   EVE_REQUIRE(p, EVE_ERR_ARG, "%s: null shape", who);
   EVE_REQUIRE(p->S > 0 && p->M > 0 && p->I > 0 && p->E > 0 && p->C > 0, EVE_ERR_ARG, "%s: bad shape S=%d M=%d I=%d E=%d C=%d",
@@ -112,6 +134,8 @@ extern "C" size_t eve_moe_workspace_bytes(const eve_moe_shape* p, int pass) {
     case EVE_MOE_PASS_INFERENCE: return fwd_ws_layout(*p, false).total;
     case EVE_MOE_PASS_FORWARD: return fwd_ws_layout(*p, true).total;
     case EVE_MOE_PASS_BACKWARD: return bwd_ws_layout(*p).total;
+    case EVE_MOE_PASS_ROUTE_FWD: return route_fwd_ws_layout(*p).total;
+    case EVE_MOE_PASS_ROUTE_BWD: return route_bwd_ws_layout(*p).total;
     default: return 0;
   }
 }
@@ -199,6 +223,93 @@ extern "C" int eve_moe_bwd(const eve_moe_shape* p, const void* dout, const float
   const bool want_t = dtext && (p->mode == EVE_MODE_VL || p->mode == EVE_MODE_TEXT);
   // route backward and gate weight gradient are independent of each other: one launch for both, one for their closing
   // sums, where the shape takes the kernels that combine (bit-identical to the two calls below)
+  if (dwg && route_wgrad_fusable(dxd, slot, dh, h, p->M, p->E, p->dtype))
+    return route_bwd_gate_wgrad(dxd, slot, dlogits, wg, dh, want_v ? dvision : nullptr, want_t ? dtext : nullptr, h, vision_embed,
+                                text_embed, dwg, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->embed_dtype, w + ws.off[WS_EMBED],
+                                eve_embed_grad_workspace_bytes(p->S, p->M), w + ws.off[WS_WGRAD],
+                                eve_gate_wgrad_workspace_bytes(p->S, p->M, p->E), stream);
+  if (int rc = eve_route_bwd(dxd, slot, dlogits, wg, dh, want_v ? dvision : nullptr, want_t ? dtext : nullptr, p->S, p->T, p->n_vis, p->mode,
+                             p->M, p->E, p->dtype, p->embed_dtype, w + ws.off[WS_EMBED], eve_embed_grad_workspace_bytes(p->S, p->M), stream)) return rc;
+  if (dwg) {
+    if (int rc = eve_gate_wgrad(h, vision_embed, text_embed, dlogits, dwg, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype,
+                                w + ws.off[WS_WGRAD], eve_gate_wgrad_workspace_bytes(p->S, p->M, p->E), stream)) return rc;
+  }
+  return EVE_OK;
+}
+
+// ------------------------------------------------------------------ expert-parallel halves (ep_size > 1)
+// The layer of one rank with the exchange and the expert FFNs cut out (they sit between the halves, on the host
+// side: RCCL all-to-all, eve_ffn_fwd/bwd on the rows received): the same kernels with the same arguments as
+// eve_moe_fwd / eve_moe_bwd enqueue around their FFN calls.  `saved` is the routing part of the blob
+// (eve_moe_saved_bytes(shape, 0)); xd / y / dy / dxd are the caller's [E*C, M] exchange buffers.
+
+extern "C" int eve_moe_route_fwd(const eve_moe_shape* p, const void* h, const void* vision_embed, const void* text_embed,
+                                 const float* wg, const float* noise, int noise_is_uniform, void* xd, float* l_aux,
+                                 void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_shape("eve_moe_route_fwd", p)) return rc;
+  EVE_REQUIRE(h && wg && noise && xd && l_aux && saved && workspace, EVE_ERR_ARG, "eve_moe_route_fwd: null pointer");
+  const Layout sv = saved_layout(*p, false), ws = route_fwd_ws_layout(*p);
+  EVE_REQUIRE(saved_bytes >= sv.total, EVE_ERR_WORKSPACE, "eve_moe_route_fwd: saved %zu < %zu (eve_moe_saved_bytes(shape, 0))", saved_bytes, sv.total);
+  EVE_REQUIRE(workspace_bytes >= ws.total, EVE_ERR_WORKSPACE, "eve_moe_route_fwd: workspace %zu < %zu (EVE_MOE_PASS_ROUTE_FWD)", workspace_bytes, ws.total);
+  EVE_REQUIRE((((uintptr_t)saved | (uintptr_t)workspace) & 255) == 0, EVE_ERR_ARG, "eve_moe_route_fwd: saved / workspace must be 256-byte aligned");
+  char* s = static_cast<char*>(saved);
+  char* w = static_cast<char*>(workspace);
+  float* logits = reinterpret_cast<float*>(w + ws.off[WS_LOGITS]);
+  int32_t* slot = reinterpret_cast<int32_t*>(s + sv.off[SV_SLOT]);
+  int32_t* slot_token = reinterpret_cast<int32_t*>(s + sv.off[SV_SLOT_TOKEN]);
+  if (int rc = eve_gate_logits_fwd(h, vision_embed, text_embed, wg, logits, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype, stream)) return rc;
+  if (int rc = eve_gate_top2_fwd(logits, noise, noise_is_uniform, p->S, p->E, p->C, reinterpret_cast<float*>(s + sv.off[SV_GATES]),
+                                 reinterpret_cast<int32_t*>(s + sv.off[SV_IDX]), reinterpret_cast<int32_t*>(s + sv.off[SV_LOC]), slot,
+                                 reinterpret_cast<float*>(s + sv.off[SV_WEIGHT]), slot_token,
+                                 reinterpret_cast<float*>(s + sv.off[SV_SLOT_WEIGHT]), reinterpret_cast<int64_t*>(s + sv.off[SV_EXP_COUNTS]),
+                                 reinterpret_cast<int32_t*>(s + sv.off[SV_ROWS]), l_aux, w + ws.off[WS_GATE],
+                                 eve_gate_workspace_bytes(p->S, p->E), stream)) return rc;
+  return eve_dispatch_fwd(h, vision_embed, text_embed, slot, slot_token, xd, p->S, p->T, p->n_vis, p->mode, p->M, p->E * p->C, p->dtype, stream);
+}
+
+extern "C" int eve_moe_finish_fwd(const eve_moe_shape* p, const void* y, const void* saved, size_t saved_bytes, void* out,
+                                  void* stream) {
+  if (int rc = check_shape("eve_moe_finish_fwd", p)) return rc;
+  EVE_REQUIRE(y && saved && out, EVE_ERR_ARG, "eve_moe_finish_fwd: null pointer");
+  const Layout sv = saved_layout(*p, false);
+  EVE_REQUIRE(saved_bytes >= sv.total, EVE_ERR_WORKSPACE, "eve_moe_finish_fwd: saved %zu < %zu", saved_bytes, sv.total);
+  const char* s = static_cast<const char*>(saved);
+  return eve_combine_fwd(y, reinterpret_cast<const int32_t*>(s + sv.off[SV_SLOT]), reinterpret_cast<const float*>(s + sv.off[SV_WEIGHT]),
+                         out, p->S, p->M, p->dtype, stream);
+}
+
+extern "C" int eve_moe_finish_bwd(const eve_moe_shape* p, const void* dout, const void* y, const void* saved, size_t saved_bytes,
+                                  void* dy, float* dweight, void* stream) {
+  if (int rc = check_shape("eve_moe_finish_bwd", p)) return rc;
+  EVE_REQUIRE(dout && y && saved && dy && dweight, EVE_ERR_ARG, "eve_moe_finish_bwd: null pointer");
+  const Layout sv = saved_layout(*p, false);
+  EVE_REQUIRE(saved_bytes >= sv.total, EVE_ERR_WORKSPACE, "eve_moe_finish_bwd: saved %zu < %zu", saved_bytes, sv.total);
+  const char* s = static_cast<const char*>(saved);
+  return eve_combine_bwd(dout, y, reinterpret_cast<const int32_t*>(s + sv.off[SV_SLOT]),
+                         reinterpret_cast<const int32_t*>(s + sv.off[SV_SLOT_TOKEN]),
+                         reinterpret_cast<const float*>(s + sv.off[SV_SLOT_WEIGHT]), dy, dweight, p->S, p->M, p->E * p->C, p->dtype, stream);
+}
+
+extern "C" int eve_moe_route_bwd(const eve_moe_shape* p, const void* dxd, const float* dweight, const float* d_l_aux, const void* h,
+                                 const void* vision_embed, const void* text_embed, const float* wg, const void* saved,
+                                 size_t saved_bytes, void* dh, float* dwg, void* dvision, void* dtext, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (int rc = check_shape("eve_moe_route_bwd", p)) return rc;
+  EVE_REQUIRE(dxd && h && wg && saved && dh && workspace, EVE_ERR_ARG, "eve_moe_route_bwd: null pointer");
+  EVE_REQUIRE(p->embed_dtype == EVE_F32 || p->embed_dtype == EVE_BF16, EVE_ERR_ARG, "eve_moe_route_bwd: bad embed_dtype %d", p->embed_dtype);
+  const Layout sv = saved_layout(*p, false), ws = route_bwd_ws_layout(*p);
+  EVE_REQUIRE(saved_bytes >= sv.total, EVE_ERR_WORKSPACE, "eve_moe_route_bwd: saved %zu < %zu", saved_bytes, sv.total);
+  EVE_REQUIRE(workspace_bytes >= ws.total, EVE_ERR_WORKSPACE, "eve_moe_route_bwd: workspace %zu < %zu (EVE_MOE_PASS_ROUTE_BWD)", workspace_bytes, ws.total);
+  EVE_REQUIRE((((uintptr_t)saved | (uintptr_t)workspace) & 255) == 0, EVE_ERR_ARG, "eve_moe_route_bwd: saved / workspace must be 256-byte aligned");
+  const char* s = static_cast<const char*>(saved);
+  char* w = static_cast<char*>(workspace);
+  const int32_t* slot = reinterpret_cast<const int32_t*>(s + sv.off[SV_SLOT]);
+  float* dlogits = reinterpret_cast<float*>(w + ws.off[WS_DLOGITS]);
+  if (int rc = eve_gate_top2_bwd(reinterpret_cast<const float*>(s + sv.off[SV_GATES]), reinterpret_cast<const int32_t*>(s + sv.off[SV_IDX]),
+                                 reinterpret_cast<const int32_t*>(s + sv.off[SV_LOC]), dweight, d_l_aux,
+                                 reinterpret_cast<const int64_t*>(s + sv.off[SV_EXP_COUNTS]), p->S, p->E, p->C, dlogits, stream)) return rc;
+  const bool want_v = dvision && (p->mode == EVE_MODE_VL || p->mode == EVE_MODE_VISION);
+  const bool want_t = dtext && (p->mode == EVE_MODE_VL || p->mode == EVE_MODE_TEXT);
   if (dwg && route_wgrad_fusable(dxd, slot, dh, h, p->M, p->E, p->dtype))
     return route_bwd_gate_wgrad(dxd, slot, dlogits, wg, dh, want_v ? dvision : nullptr, want_t ? dtext : nullptr, h, vision_embed,
                                 text_embed, dwg, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->embed_dtype, w + ws.off[WS_EMBED],

@@ -860,15 +860,16 @@ __global__ __launch_bounds__(512) void gate_logits_walk_kernel(const bf16_t* __r
   int kof[KB];
 #pragma unroll
   for (int u = 0; u < KB; ++u) kof[u] = min(k_lo + 16 * u, M - 16) + 8 * hh;
-  Vec16<bf16_t> xa0[KB], xa1[KB];  // (two named buffers: a dynamically indexed array would live in scratch memory)
-  auto load_tile = [&](int t, Vec16<bf16_t> (&dst)[KB]) {
-    const int s = min(t * 32 + i, S - 1);
-    const bf16_t* hp = h + (size_t)s * M;
+  // rows of the tile being multiplied (cur) and of the next one (nxt, in flight meanwhile)
+  uint4 cur[KB], nxt[KB];
+  {
+    const bf16_t* hp = h + (size_t)min(t_begin * 32 + i, S - 1) * M;
 #pragma unroll
-    for (int u = 0; u < KB; ++u) dst[u] = load16<bf16_t>(hp + kof[u]);
-  };
-  load_tile(t_begin, xa0);
-  if (t_begin + 1 < t_end) load_tile(t_begin + 1, xa1);
+    for (int u = 0; u < KB; ++u) cur[u] = *reinterpret_cast<const uint4*>(hp + kof[u]);
+    const bf16_t* hq = h + (size_t)min((t_begin + 1) * 32 + i, S - 1) * M;  // (clamped: unused past the last tile)
+#pragma unroll
+    for (int u = 0; u < KB; ++u) nxt[u] = *reinterpret_cast<const uint4*>(hq + kof[u]);
+  }
   // my slice of wg (expert i), split once
   gate_bf16x8 bh[KB], bm[KB], bl[KB];
   {
@@ -881,32 +882,47 @@ __global__ __launch_bounds__(512) void gate_logits_walk_kernel(const bf16_t* __r
       split3_bf16(b, bh[u], bm[u], bl[u]);
     }
   }
-  auto tile = [&](int t, Vec16<bf16_t> (&x)[KB]) {
+  for (int t = t_begin; t < t_end; ++t) {
+    uint4 ev[KB];
     if constexpr (EMB) {
       const int s = min(t * 32 + i, S - 1);
       const bf16_t* emb = token_modality(s, T_, n_vis, mode) ? temb : vemb;
-      Vec16<bf16_t> ev[KB];
 #pragma unroll
-      for (int u = 0; u < KB; ++u) ev[u] = load16<bf16_t>(emb + kof[u]);
-#pragma unroll
-      for (int u = 0; u < KB; ++u) {
-        float xs[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xs[j] = x[u].get(j) + ev[u].get(j);
-        x[u].set_all(xs);
-      }
+      for (int u = 0; u < KB; ++u) ev[u] = *reinterpret_cast<const uint4*>(emb + kof[u]);
     }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-      const gate_bf16x8 av = __builtin_bit_cast(gate_bf16x8, x[u].raw);
+      uint4 raw = cur[u];
+      if constexpr (EMB) {  // x = bf16(h + embed), one rounding
+        const uint32_t *xw = &raw.x, *ew = &ev[u].x;
+        uint32_t o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float lo = __uint_as_float(xw[p] << 16) + __uint_as_float(ew[p] << 16);
+          const float hi = __uint_as_float(xw[p] & 0xffff0000u) + __uint_as_float(ew[p] & 0xffff0000u);
+          typedef __attribute__((ext_vector_type(2))) float f2;
+          typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+          const f2 pr = {lo, hi};
+          o[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, b2));
+        }
+        raw = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+      const gate_bf16x8 av = __builtin_bit_cast(gate_bf16x8, raw);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bl[u], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm[u], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh[u], acc, 0, 0, 0);
     }
-    if (t + 2 < t_end) load_tile(t + 2, x);  // the buffer just consumed takes the tile after next
+    // next tile's rows move up (they have had this tile's multiply to land); the tile after it goes out
+#pragma unroll
+    for (int u = 0; u < KB; ++u) cur[u] = nxt[u];
+    if (t + 2 < t_end) {
+      const bf16_t* hq = h + (size_t)min((t + 2) * 32 + i, S - 1) * M;
+#pragma unroll
+      for (int u = 0; u < KB; ++u) nxt[u] = *reinterpret_cast<const uint4*>(hq + kof[u]);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
@@ -923,10 +939,6 @@ __global__ __launch_bounds__(512) void gate_logits_walk_kernel(const bf16_t* __r
       }
     }
     __syncthreads();
-  };
-  for (int t = t_begin; t < t_end; t += 2) {
-    tile(t, xa0);
-    if (t + 1 < t_end) tile(t + 1, xa1);
   }
 }
 

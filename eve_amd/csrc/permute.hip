@@ -692,7 +692,8 @@ __device__ __forceinline__ void route_bwd_bf16_body(const bf16_t* __restrict__ d
         dhi[ks][j] = hb;
         dlo[ks][j] = static_cast<__bf16>(v - static_cast<float>(hb));
       }
-    const unsigned tm = (unsigned)__ballot(lane < 32 && s0 + t < S && token_modality(min(s0 + t, S - 1), T_, n_vis, mode) != 0);
+    // (only the column sums by modality read it; without them T_ may be 0 and token_modality would divide by it)
+    const unsigned tm = part ? (unsigned)__ballot(lane < 32 && s0 + t < S && token_modality(min(s0 + t, S - 1), T_, n_vis, mode) != 0) : 0u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       f32x16_t acc;

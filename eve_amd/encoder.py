@@ -77,6 +77,41 @@ class _ScaleResidualFn(torch.autograd.Function):
         return dx.view(B, T, M), dgamma, None, dout
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension on the library's LayerNorm kernels (the single-group case of
+    eve_split_ln_fwd/bwd): one pass forward, one pass + a fixed-order column sum backward, instead of the stock
+    forward kernel, two backward kernels and the reduce kernels of the affine gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):  # type: ignore[override]
+        from . import ops
+        shape = x.shape
+        x2 = x.contiguous().view(-1, shape[-1])
+        g = weight.to(x.dtype).contiguous()
+        y, mean, rstd = ops.layer_norm_fwd(x2, g, bias.to(x.dtype).contiguous(), eps)
+        ctx.save_for_backward(x2, mean, rstd, g)
+        ctx.param_dtypes = (weight.dtype, bias.dtype)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):  # type: ignore[override]
+        from . import ops
+        x2, mean, rstd, g = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.layer_norm_bwd(dy.contiguous().view(x2.shape), x2, mean, rstd, g)
+        wdt, bdt = ctx.param_dtypes
+        return dx.view(dy.shape), dgamma.to(wdt), dbeta.to(bdt), None
+
+
+def layer_norm(mod: nn.LayerNorm, x: Tensor) -> Tensor:
+    """`mod(x)` (reference norm1 / norm2_vl / norm2_imag, multiway_transformer.py:338, :350): on the GPU through the
+    library's kernels where their shape limits hold (rows of up to 1024 elements in one wave's registers), else stock."""
+    M = x.shape[-1]
+    if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and mod.elementwise_affine and mod.bias is not None
+            and tuple(mod.normalized_shape) == (M,) and M % 8 == 0 and M <= 1024 and x.numel() > 0):
+        return _LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps)
+    return mod(x)
+
+
 class Attention(nn.Module):
     """Reference :57-132.  `qkv` has no bias of its own; `q_bias` / `v_bias` are separate parameters (the key
     bias is fixed at zero), as in BEiT."""
@@ -188,20 +223,23 @@ class MultiwayTransformerEnocderLayer(nn.Module):
             raise NotImplementedError
         moe_layer = self.use_ffn and self.ffn_type == 'moe'
         if moe_layer:
-            return self._moe(self.norm2_vl(h), mode=mode)
+            return self._moe(layer_norm(self.norm2_vl, h), mode=mode)
         if mode == 'vl' and self.use_ffn:
-            return self.mlp_vl(self.norm2_vl(h))
+            return self.mlp_vl(layer_norm(self.norm2_vl, h))
         kind = self.single_ffn['type']
         if kind == 'single':
-            return self.mlp_imag(self.norm2_imag(h))
+            return self.mlp_imag(layer_norm(self.norm2_imag, h))
         if kind == 'moe':
-            return self._moe(self.norm2_imag(h))  # the reference passes no mode here (:362)
+            return self._moe(layer_norm(self.norm2_imag, h))  # the reference passes no mode here (:362)
         return self._split(h, mode=mode)
 
     def _branch(self, residual: Tensor, x: Tensor, gamma) -> Tensor:
         """`residual + self.drop_path(x * gamma)` (reference :341, :408): on the GPU one fused pass."""
+        # the fused pass keeps x's dtype: a gamma of another dtype (fp32 layer scale on bf16 activations promotes the
+        # reference's product to fp32) or shape, or a row too wide for the backward's LDS, takes the stock ops
+        gamma_ok = not isinstance(gamma, Tensor) or (gamma.dtype == x.dtype and tuple(gamma.shape) == (x.shape[-1],))
         if not (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and x.dtype == residual.dtype
-                and x.shape == residual.shape and x.shape[-1] % 8 == 0):
+                and x.shape == residual.shape and x.shape[-1] % 8 == 0 and x.shape[-1] <= 16384 and gamma_ok):
             return residual + self.drop_path(x * gamma)
         row_scale = None
         p = getattr(self.drop_path, "drop_prob", 0.0)
@@ -214,7 +252,7 @@ class MultiwayTransformerEnocderLayer(nn.Module):
 
     def forward(self, hidden_states: Tensor, attention_mask=None, relative_position_bias=None, mode='vl') -> Tensor:
         residual = hidden_states
-        hidden_states = self.attn(self.norm1(hidden_states), mask=attention_mask,
+        hidden_states = self.attn(layer_norm(self.norm1, hidden_states), mask=attention_mask,
                                   relative_position_bias=relative_position_bias)
         hidden_states = self._branch(residual, hidden_states, self.gamma_1)
         residual = hidden_states

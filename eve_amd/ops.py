@@ -329,6 +329,33 @@ def split_ln_bwd(dxg, h, mean, rstd, gamma_v, gamma_t, n_vis: int):
     return dh, dparams
 
 
+def layer_norm_fwd(x2d, gamma, beta, eps: float):
+    """Plain LayerNorm over the last dimension of x [S,M] on the split-LayerNorm kernel with a single group (every
+    token "vision": row s of the input is row s of the output; the second group does not exist and is never touched).
+    -> (y [S,M], mean [S], rstd [S])"""
+    _chk(x2d, "x"), _chk(gamma, "weight", x2d.dtype), _chk(beta, "bias", x2d.dtype)
+    S, M = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(S, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(S, dtype=torch.float32, device=x2d.device)
+    PROFILE.call("eve_split_ln_fwd", _p(x2d), _p(gamma), _p(beta), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
+                 1, S, S, S, M, float(eps), _dt(x2d), _stream(), tag="plain")
+    return y, mean, rstd
+
+
+def layer_norm_bwd(dy2d, x2d, mean, rstd, gamma):
+    """-> (dx [S,M], dgamma [M] fp32, dbeta [M] fp32)."""
+    _chk(dy2d, "dy", x2d.dtype), _chk(x2d, "x"), _chk(gamma, "weight", x2d.dtype)
+    S, M = x2d.shape
+    dx = torch.empty_like(x2d)
+    dparams = torch.empty(4, M, dtype=torch.float32, device=x2d.device)
+    nbytes = _lib.load().eve_split_ln_workspace_bytes(S, M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
+    PROFILE.call("eve_split_ln_bwd", _p(dy2d), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(gamma), _p(dx), _p(dparams),
+                 1, S, S, S, M, _dt(x2d), _p(ws), nbytes, _stream(), tag="plain")
+    return dx, dparams[0], dparams[1]
+
+
 def split_permute(src, B: int, T: int, n_vis: int, R: int, to_groups: bool):
     _chk(src, "src")
     M = src.shape[-1]

@@ -87,7 +87,12 @@ def merge_score_matrix(block: Tensor, n_rows: int, group=None, dst: Optional[int
     what `evaluation` returns, Retrieval.py:193-205) or on rank `dst` of the group only (others get None).
 
     `reference_offset`: add the `FILL * (world - 1)` that the reference's SUM all-reduce of FILL-initialised
-    matrices leaves on every entry (see the module docstring); False gives the un-shifted scores."""
+    matrices leaves on every entry (see the module docstring); False gives the un-shifted scores.  The shifted
+    matrix agrees with the reference's to fp32 ROUNDING, not bit for bit: the reference adds -100 once per peer in ring
+    order, here the whole constant is one fp32 add, and at magnitude 100 * (world - 1) (ulp 6e-5 at 700) the two can
+    round differently for world > 2 -- near-tied scores may then rank differently.  The constant is the same for every
+    entry of a row, so it changes no ranking metric: prefer `reference_offset=False` (scores at full precision) for
+    itm_eval-style evaluation and keep True only where the reference's absolute values are wanted."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         assert block.shape[0] == n_rows
         return block

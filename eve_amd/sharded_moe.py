@@ -408,7 +408,8 @@ def _fused_plan(key: tuple):
         shape = _lib.MoEShape(*key)
         ref = ctypes.addressof(shape)
         ws = {p: int(lib.eve_moe_workspace_bytes(ref, p)) for p in
-              (_lib.MOE_PASS_INFERENCE, _lib.MOE_PASS_FORWARD, _lib.MOE_PASS_BACKWARD)}
+              (_lib.MOE_PASS_INFERENCE, _lib.MOE_PASS_FORWARD, _lib.MOE_PASS_BACKWARD, _lib.MOE_PASS_ROUTE_FWD,
+               _lib.MOE_PASS_ROUTE_BWD)}
         saved = {}
         n = len(_lib.MOE_SAVED_FIELDS)
         for nb in (0, 1):
@@ -508,6 +509,120 @@ class _FusedMoEFn(torch.autograd.Function):
         if dte is not None and dte.dtype != t_dt:
             dte = dte.to(t_dt)
         return (dh, dwg, dv, dte, None, dw1, db1, dw2, db2) + (None,) * 7
+
+
+
+class _EPRouteFn(torch.autograd.Function):
+    """Everything of the layer BEFORE the first exchange, one C call per direction (eve_moe_route_fwd / _bwd):
+    modality add + gate Linear -> top-2 gating -> dispatch forward; gate backward -> dispatch backward + gate weight
+    gradient + modality-embedding gradients backward.  Same kernels and results as `_RouteDispatchFn` (reference
+    sharded_moe.py:350-367).  Returns the dispatched rows, the combine weights (a view into the routing blob, the
+    differentiable link to `_EPFinishFn`), l_aux and the views the module exposes; the routing blob itself is left in
+    `holder["blob"]`."""
+
+    @staticmethod
+    def forward(ctx, h, wg, vemb, temb, noise, key, noise_is_uniform, holder):  # type: ignore[override]
+        B, T, M = h.shape
+        S, E, C = key[0], key[6], key[7]
+        h2d = h.contiguous().view(S, M)
+        wg32 = _cast(wg, torch.float32)
+        ve, te = _cast(vemb, h.dtype), _cast(temb, h.dtype)
+        noise = noise.contiguous()
+        ops._chk(h2d, "hidden"), ops._chk(wg32, "wg", torch.float32), ops._chk(noise, "noise", torch.float32)
+        ops._chk(ve, "vision_embed", h.dtype), ops._chk(te, "text_embed", h.dtype)
+        if noise.shape != (S, E) or tuple(wg32.shape) != (E, M):
+            raise RuntimeError("eve_amd: gate parameter / noise shapes do not match the layer input")
+        v_dt = None if vemb is None else vemb.dtype
+        t_dt = None if temb is None else temb.dtype
+        fused_dt = torch.bfloat16 if key[10] == _lib.BF16 else torch.float32
+        _, ref, ws_bytes, saved_plan = _fused_plan(key)
+        nbytes, offs = saved_plan[0]
+        dev = h.device
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nws = ws_bytes[_lib.MOE_PASS_ROUTE_FWD]
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        xd = torch.empty(E * C, M, dtype=h.dtype, device=dev)
+        l_aux = torch.empty((), dtype=torch.float32, device=dev)
+        ops.PROFILE.call("eve_moe_route_fwd", ref, ops._p(h2d), ops._p(ve), ops._p(te), ops._p(wg32), ops._p(noise),
+                         1 if noise_is_uniform else 0, ops._p(xd), ops._p(l_aux), ops._p(blob), nbytes, ops._p(ws), nws,
+                         ops._stream())
+        view = lambda name, n, dt: blob[offs[name]:offs[name] + n].view(dt)
+        weight = view("weight", S * 8, torch.float32).view(S, 2)
+        slot = view("slot", S * 8, torch.int32).view(S, 2)
+        exp_counts = view("exp_counts", E * 8, torch.int64)
+        ctx.save_for_backward(h2d, wg32, ve, te, blob)
+        ctx.key, ctx.dims = key, (B, T, M, E)
+        ctx.param_dtypes = (wg.dtype, v_dt, t_dt, fused_dt)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(slot, exp_counts)
+        holder["blob"] = blob  # (not an output: `weight`, `slot` and `exp_counts` are views into it)
+        return xd, weight, l_aux, slot, exp_counts
+
+    @staticmethod
+    def backward(ctx, dxd, d_weight, d_l_aux, *unused):  # type: ignore[override]
+        h2d, wg32, ve, te, blob = ctx.saved_tensors
+        B, T, M, E = ctx.dims
+        S = B * T
+        mode, C = ctx.key[3], ctx.key[7]
+        _, ref, ws_bytes, _ = _fused_plan(ctx.key)
+        dev, dt = h2d.device, h2d.dtype
+        wg_dt, v_dt, t_dt, fused_dt = ctx.param_dtypes
+        dxd = torch.zeros(E * C, M, dtype=dt, device=dev) if dxd is None else dxd.contiguous()
+        ops._chk(dxd, "dxd", dt)
+        if d_weight is not None:
+            d_weight = d_weight.contiguous()
+        ops._chk(d_weight, "d_weight", torch.float32)
+        dl = None if d_l_aux is None else d_l_aux.reshape(1).float().contiguous()
+        need = ctx.needs_input_grad
+        want_v = mode in (_lib.MODE_VL, _lib.MODE_VISION) and need[2]
+        want_t = mode in (_lib.MODE_VL, _lib.MODE_TEXT) and need[3]
+        dh = torch.empty(B, T, M, dtype=dt, device=dev)
+        dwg = torch.empty(E, M, dtype=torch.float32, device=dev) if need[1] else None
+        dv = torch.empty(M, dtype=fused_dt, device=dev) if want_v else None
+        dte = torch.empty(M, dtype=fused_dt, device=dev) if want_t else None
+        nws = ws_bytes[_lib.MOE_PASS_ROUTE_BWD]
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        ops.PROFILE.call("eve_moe_route_bwd", ref, ops._p(dxd), ops._p(d_weight), ops._p(dl), ops._p(h2d), ops._p(ve),
+                         ops._p(te), ops._p(wg32), ops._p(blob), blob.numel(), ops._p(dh), ops._p(dwg), ops._p(dv),
+                         ops._p(dte), ops._p(ws), nws, ops._stream())
+        if dwg is not None and dwg.dtype != wg_dt:
+            dwg = dwg.to(wg_dt)
+        if dv is not None and dv.dtype != v_dt:
+            dv = dv.to(v_dt)
+        if dte is not None and dte.dtype != t_dt:
+            dte = dte.to(t_dt)
+        return dh, dwg, dv, dte, None, None, None, None
+
+
+class _EPFinishFn(torch.autograd.Function):
+    """Everything AFTER the second exchange: the combine (reference sharded_moe.py:377) on the routing blob of
+    `_EPRouteFn`, one C call per direction (eve_moe_finish_fwd / _bwd).  `weight` is the blob's view: it carries the
+    gradient of the combine weights back to the gate."""
+
+    @staticmethod
+    def forward(ctx, y, weight, blob, key):  # type: ignore[override]
+        S, M = key[0], key[4]
+        y = y.contiguous()
+        _, ref, _, _ = _fused_plan(key)
+        out = torch.empty(S, M, dtype=y.dtype, device=y.device)
+        ops._chk(y, "expert_output")
+        ops.PROFILE.call("eve_moe_finish_fwd", ref, ops._p(y), ops._p(blob), blob.numel(), ops._p(out), ops._stream())
+        ctx.save_for_backward(y, blob)
+        ctx.key = key
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):  # type: ignore[override]
+        y, blob = ctx.saved_tensors
+        S = ctx.key[0]
+        _, ref, _, _ = _fused_plan(ctx.key)
+        dout = dout.contiguous().view(S, -1)
+        ops._chk(dout, "dout", y.dtype)
+        dy = torch.empty_like(y)
+        dw = torch.empty(S, 2, dtype=torch.float32, device=y.device)
+        ops.PROFILE.call("eve_moe_finish_bwd", ref, ops._p(dout), ops._p(y), ops._p(blob), blob.numel(), ops._p(dy),
+                         ops._p(dw), ops._stream())
+        return dy, dw, None, None
 
 
 # -------------------------------------------------------------------------- functional
@@ -634,6 +749,10 @@ class MOELayer(nn.Module):
         # ep_size == 1: issue the layer as one C call per direction (eve_moe_fwd / eve_moe_bwd).  False = one call
         # per stage (same kernels and results; what the per-call HIP-event profile of bench.py times).
         self.fused_call = True
+        # the two halves around the exchange as one C call each per direction (eve_moe_route_* / eve_moe_finish_*): what
+        # an expert-parallel layer runs; True on a single rank selects them too (the exchange is then the identity;
+        # tests compare the three call forms bit for bit)
+        self.split_call = False
         self._graph_counts_host: Optional[Tensor] = None
         self.l_aux = None
         self.exp_counts = None
@@ -678,6 +797,51 @@ class MOELayer(nn.Module):
             self.ep_group = dist.group.WORLD
         return self.ep_group
 
+    def _forward_halves(self, h, orig_shape, vemb_in, temb_in, noise, is_uniform, n_vis, code, E):
+        """The expert-parallel form of the layer: route half -> exchange -> expert FFNs -> exchange -> finish half
+        (reference sharded_moe.py:345-381 with the `_AllToAll`s of :84-100 live).  Six foreign calls per step plus
+        the collectives; peers' fill counts are not exchanged, so every capacity row received is processed."""
+        from .experts import _GroupedFFNFn
+        gate = self.gate
+        B, T, M = h.shape
+        S = B * T
+        C = ops.capacity(S, E, gate.active_capacity_factor(), gate.min_capacity)
+        v_dt = None if vemb_in is None else vemb_in.dtype
+        t_dt = None if temb_in is None else temb_in.dtype
+        e_dt = v_dt if v_dt is not None else t_dt
+        fused_dt = e_dt if e_dt in (torch.float32, torch.bfloat16) and v_dt in (None, e_dt) and t_dt in (None, e_dt) \
+            else torch.float32
+        act = self.experts._act_code
+        # (the halves never read I: the plan is keyed with I = M)
+        key = (S, T, n_vis, code, M, M, E, C, act, ops._dt(h), ops._DTYPES[fused_dt])
+        holder: Dict[str, Tensor] = {}
+        xd, weight, l_aux, slot, exp_counts = _EPRouteFn.apply(h, gate.wg.weight, vemb_in, temb_in, noise, key, is_uniform,
+                                                               holder)
+        blob = holder["blob"]
+        self.l_aux = l_aux
+        self.exp_counts = self._host_counts(exp_counts)
+        self.last_slot = slot.clone()
+        group = self._resolve_ep_group()
+        w1, b1, w2, b2 = self.experts.packed_parameters(xd.dtype)
+        ep, e_l = self.ep_size, self.num_local_experts
+        xd4 = xd.view(ep, e_l, C, M)
+        nch = ep_chunks(e_l) if group is not None else 1
+        if group is not None and nch > 1:  # pipelined exchange / FFN / exchange over chunks of the local experts
+            y = _EPPipelineFn.apply(group, nch, act, xd4, w1, b1, w2, b2)
+        else:
+            if group is not None:
+                x_in = _AllToAll.apply(group, xd4.view(ep, -1)).view(ep * e_l, C, M)
+                rows = None
+            else:  # a single rank (split_call): the routing blob's fill counts bound the rows the GEMMs touch
+                x_in = xd4.view(ep * e_l, C, M)
+                o = _fused_plan(key)[3][0][1]["rows"]
+                rows = blob[o:o + E * 4].view(torch.int32)
+            y = _GroupedFFNFn.apply(x_in, w1, b1, w2, b2, rows, act)
+            if group is not None:
+                y = _AllToAll.apply(group, y.reshape(ep, -1))
+        out = _EPFinishFn.apply(y.reshape(E * C, M), weight, blob, key)
+        return out.view(orig_shape)
+
     def forward(self, *input: Tensor, mode='vl', **kwargs: Any) -> Tensor:
         h = input[0]
         if not h.is_cuda:
@@ -713,7 +877,7 @@ class MOELayer(nn.Module):
                                       "supported through TopKGate.forward")
         n_vis = int(self.num_vision_tokens) if has_embed else 0
 
-        if (self.ep_size == 1 and self.fused_call and not ops.PROFILE.on
+        if (self.ep_size == 1 and self.fused_call and not self.split_call and not ops.PROFILE.on
                 and getattr(self.experts, "packed_parameters", None) is not None and E == self.num_local_experts
                 and E <= 32):
             # every expert is local: the whole layer is one C call per direction (eve_moe_fwd / eve_moe_bwd)
@@ -727,6 +891,11 @@ class MOELayer(nn.Module):
             # alive on the module after backward, until this layer's next forward
             self.last_slot = slot.clone()
             return out.view(orig_shape)
+
+        packed = getattr(self.experts, "packed_parameters", None) is not None
+        if ((self.ep_size > 1 or self.split_call) and self.fused_call and not ops.PROFILE.on and packed and E <= 32
+                and E == self.num_local_experts * self.ep_size):
+            return self._forward_halves(h, orig_shape, vemb_in, temb_in, noise, is_uniform, n_vis, code, E)
 
         xd, weight, l_aux, slot, slot_token, slot_weight, rows, exp_counts = _RouteDispatchFn.apply(
             h, gate.wg.weight, vemb_in, temb_in, noise, n_vis, code, gate.active_capacity_factor(), gate.min_capacity,

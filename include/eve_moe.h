@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 8
+#define EVE_MOE_ABI_VERSION 9
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -242,7 +242,7 @@ size_t eve_ffn_bwd_workspace_bytes(int G, int E_local, int R, int M, int I, int 
  *   workspace  eve_moe_workspace_bytes(shape, pass): scratch of ONE call (logits, gate scratch, dy / dz / dxd,
  *              dlogits, the reductions' partials); contents irrelevant before, garbage after.
  * Both 256-byte aligned device memory.  Expert-parallel layers (ep_size > 1) have a collective between dispatch and
- * the FFNs and use the per-stage entry points. */
+ * the FFNs: they use the two halves further down (eve_moe_route_fwd ... eve_moe_route_bwd) around eve_ffn_fwd/bwd. */
 typedef struct eve_moe_shape {
   int S;           /* tokens B*T                                                                       */
   int T;           /* tokens per sample (modality split of mode VL); ignored for EVE_MODE_NONE          */
@@ -256,7 +256,8 @@ typedef struct eve_moe_shape {
   int embed_dtype; /* element type the modality-embedding GRADIENTS are stored as (eve_route_bwd)       */
 } eve_moe_shape;
 
-enum { EVE_MOE_PASS_INFERENCE = 0, EVE_MOE_PASS_FORWARD = 1, EVE_MOE_PASS_BACKWARD = 2 };
+enum { EVE_MOE_PASS_INFERENCE = 0, EVE_MOE_PASS_FORWARD = 1, EVE_MOE_PASS_BACKWARD = 2,
+       EVE_MOE_PASS_ROUTE_FWD = 3, EVE_MOE_PASS_ROUTE_BWD = 4 /* the expert-parallel halves below */ };
 
 /* order of eve_moe_saved_offsets' output; the last four exist only with need_backward (offset (size_t)-1 otherwise) */
 enum {
@@ -299,6 +300,37 @@ int eve_moe_bwd(const eve_moe_shape* shape, const void* dout, const float* d_l_a
                 const void* vision_embed, const void* text_embed, const float* wg, const void* w1, const void* w2,
                 const void* saved, size_t saved_bytes, void* dh, float* dwg, void* dvision, void* dtext, void* dw1,
                 void* db1, void* dw2, void* db2, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------- the layer's two halves under expert parallelism (ep_size > 1)
+ *
+ * MOELayer.forward with the all-to-all exchanges of models/sharded_moe.py:368-379 (`_AllToAll`, :84-100) between
+ * dispatch and the experts and between the experts and combine: everything BEFORE the first exchange and everything
+ * AFTER the second one as one call each per direction, so that an expert-parallel step is about six foreign calls
+ * (these four + eve_ffn_fwd + eve_ffn_bwd per chunk of local experts) plus the collectives, instead of one call per
+ * stage.  Same kernels, same arguments, same results as the per-stage entry points (and as eve_moe_fwd / eve_moe_bwd
+ * around their FFN calls).  `saved` here is the ROUTING part of the blob only, eve_moe_saved_bytes(shape, 0) with the
+ * offsets of eve_moe_saved_offsets(shape, 0, ...); xd, y, dy and dxd are the caller's [E*C, M] exchange buffers in the
+ * reference's [ep, E_local, C, M] layout (:370).  shape->E is the GLOBAL expert count, shape->I is not used.
+ *
+ *   eve_moe_route_fwd   eve_gate_logits_fwd -> eve_gate_top2_fwd -> eve_dispatch_fwd: xd [E*C,M], l_aux [1]; workspace
+ *                       EVE_MOE_PASS_ROUTE_FWD
+ *   eve_moe_finish_fwd  eve_combine_fwd of the expert outputs y [E*C,M] that came back: out [S,M]
+ *   eve_moe_finish_bwd  eve_combine_bwd: dy [E*C,M] (to be sent to the experts' owners), dweight [S,2] fp32
+ *   eve_moe_route_bwd   eve_gate_top2_bwd -> eve_route_bwd + eve_gate_wgrad on dxd [E*C,M] (the experts' input gradient
+ *                       that came back), dweight (from eve_moe_finish_bwd; NULL = none) and d_l_aux [1] (NULL = none):
+ *                       dh [S,M], dwg [E,M] fp32 (NULL = not wanted), dvision / dtext [M] as shape->embed_dtype (NULL =
+ *                       not wanted); workspace EVE_MOE_PASS_ROUTE_BWD */
+int eve_moe_route_fwd(const eve_moe_shape* shape, const void* h, const void* vision_embed, const void* text_embed,
+                      const float* wg, const float* noise, int noise_is_uniform, void* xd, float* l_aux, void* saved,
+                      size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int eve_moe_finish_fwd(const eve_moe_shape* shape, const void* y, const void* saved, size_t saved_bytes, void* out,
+                       void* stream);
+int eve_moe_finish_bwd(const eve_moe_shape* shape, const void* dout, const void* y, const void* saved, size_t saved_bytes,
+                       void* dy, float* dweight, void* stream);
+int eve_moe_route_bwd(const eve_moe_shape* shape, const void* dxd, const float* dweight, const float* d_l_aux,
+                      const void* h, const void* vision_embed, const void* text_embed, const float* wg,
+                      const void* saved, size_t saved_bytes, void* dh, float* dwg, void* dvision, void* dtext,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------- hard modality split of the non-MoE layers
  * Reference models/multiway_transformer.py:366-370: vision positions [:, :n_vis] go through

@@ -16,8 +16,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(moe, h, dout, noise, mode, fused, train=True):
+def _run(moe, h, dout, noise, mode, fused, train=True, split=False):
     moe.moe.fused_call = fused
+    moe.moe.split_call = split
     for p in moe.parameters():
         p.grad = None
     moe.moe.noise_override = noise.clone()
@@ -54,10 +55,17 @@ def test_fused_calls_equal_the_per_stage_calls_bit_for_bit(dtype, mode, n_vis):
         assert (x is None) == (y is None), i
         if x is not None:
             assert x.dtype == y.dtype and torch.equal(x, y), f"result {i} differs"
+    # the expert-parallel halves (eve_moe_route_* / eve_moe_finish_* around eve_ffn_*), here with the identity exchange
+    c = _run(moe, h, dout, noise, mode, fused=True, split=True)
+    for i, (x, y) in enumerate(zip(c, b)):
+        assert (x is None) == (y is None), i
+        if x is not None:
+            assert x.dtype == y.dtype and torch.equal(x, y), f"halves: result {i} differs"
     ai = _run(moe, h, dout, noise, mode, fused=True, train=False)
     bi = _run(moe, h, dout, noise, mode, fused=False, train=False)
-    for i, (x, y) in enumerate(zip(ai, bi)):
-        assert torch.equal(x, y), f"inference result {i} differs"
+    ci = _run(moe, h, dout, noise, mode, fused=True, train=False, split=True)
+    for i, (x, y, z) in enumerate(zip(ai, bi, ci)):
+        assert torch.equal(x, y) and torch.equal(z, y), f"inference result {i} differs"
     assert torch.equal(ai[0], a[0])  # inference (activations in the workspace, z not stored) == training forward
 
 
@@ -72,10 +80,12 @@ def test_fused_calls_at_model_dims_bf16_equal_the_per_stage_calls():
     noise = orc.gumbel_noise((B * T, E), generator=g).to(DEV)
     a = _run(moe, h, dout, noise, "vl", fused=True)
     b = _run(moe, h, dout, noise, "vl", fused=False)
-    for i, (x, y) in enumerate(zip(a, b)):
-        assert (x is None) == (y is None), i
+    c = _run(moe, h, dout, noise, "vl", fused=True, split=True)
+    for i, (x, y, z) in enumerate(zip(a, b, c)):
+        assert (x is None) == (y is None) == (z is None), i
         if x is not None:
             assert torch.equal(x, y), f"result {i} differs"
+            assert torch.equal(z, y), f"halves: result {i} differs"
 
 
 def test_fused_entry_points_reject_small_buffers_and_bad_shapes():
