@@ -86,6 +86,11 @@ struct MfmaDesc {
   // 2 560 text rows): tiles are enumerated over the rows that exist (tile_of_block) instead of over
   // G x ceil(Mext / BM) slots, most of which would be empty for the short group and leave its XCDs idle
   int compact;
+  // tile order inside a group: 0 = row tile fastest (consecutive tiles share their B column panel), 1 = column tile
+  // fastest (they share their A row panel).  The panel to share is the one of the LARGER operand: the smaller one
+  // stays in the XCD's L2 anyway.  dw1 = dz^T x has A = dz [rows, I] four times the size of B = x [rows, M]: walked
+  // row tile fastest, its twelve A panels (5.8 MB per expert, more than the 4 MiB L2) were fetched three times over.
+  int nfast;
   // weight-gradient launches of such groups (one K segment per expert, rows[] given): expert e's K range is cut
   // into ceil(rows[e] / L) equal slices, L = ceil(sum of rows / kslots) -- at most kslots + E_local slices in all,
   // numbered expert-major -- each with an fp32 partial Cpart[slice][Mext][N]; wgrad_reduce_dyn_kernel adds an
@@ -158,7 +163,8 @@ __device__ __forceinline__ bool tile_of_block(const MfmaDesc& d, unsigned bid, T
     const int ep = d.G / d.E_local;
     T.z = (p % ep) * d.E_local + p / ep;  // p enumerates (expert, source) pairs expert-major
   }
-  T.m0 = (tile % tiles_m) * BM; T.n0 = (tile / tiles_m) * BN;
+  if (WGRAD && d.nfast) { T.n0 = (tile % tiles_n) * BN; T.m0 = (tile / tiles_n) * BM; }
+  else { T.m0 = (tile % tiles_m) * BM; T.n0 = (tile / tiles_m) * BN; }
   T.mext = d.Mext;
   if (!WGRAD && d.rows) T.mext = min(T.mext, d.rows[T.z]);
   return T.m0 < T.mext;
@@ -799,7 +805,9 @@ __device__ __forceinline__ void pp_tile(const MfmaPair& pr, char* smem) {
       sl -= ns;
     }
     z = e; zpart = p;
-    m0 = (tile % tiles_m) * BM; n0 = (tile / tiles_m) * BN; mext = d.Mext;
+    if (d.nfast) { const int tiles_n = d.N / BN; n0 = (tile % tiles_n) * BN; m0 = (tile / tiles_n) * BM; }
+    else { m0 = (tile % tiles_m) * BM; n0 = (tile / tiles_m) * BN; }
+    mext = d.Mext;
     kchunk = ((rows_e + ns - 1) / ns + BKI - 1) / BKI * BKI;
     kbase = sl * kchunk;
     seg_hi = 1;
@@ -1623,9 +1631,10 @@ static int cu_count() {  // of the current device; cached per device
 //   EVE_FFN_WGRAD32=1          32-deep persistent weight-gradient kernel for all tiles
 //   EVE_FFN_WGRAD_PERSIST=1    persistent 64-deep kernel for the (unsplit) weight-gradient launch (measured in round 3:
 //                              eve_ffn_bwd 0.646 ms against 0.595 ms with one tile per workgroup -- it spills)
+//   EVE_FFN_NFAST=0            weight gradients: row tile fastest for both GEMMs (MfmaDesc::nfast off)
 //   EVE_FFN_COMPACT=0          few unequal groups: the plain G x ceil(R / BM) tile enumeration and equal K splits
 struct Knobs {
-  bool pingpong, persist, persist_act, wgrad32, wgrad_persist, compact;
+  bool pingpong, persist, persist_act, wgrad32, wgrad_persist, compact, nfast;
   int tile_rows, ksplit;
 };
 static const Knobs& knobs() {
@@ -1639,12 +1648,13 @@ static const Knobs& knobs() {
     q.wgrad32 = env("EVE_FFN_WGRAD32") != nullptr;
     q.wgrad_persist = env("EVE_FFN_WGRAD_PERSIST") && env("EVE_FFN_WGRAD_PERSIST")[0] == '1';
     q.compact = !(env("EVE_FFN_COMPACT") && env("EVE_FFN_COMPACT")[0] == '0');
+    q.nfast = !(env("EVE_FFN_NFAST") && env("EVE_FFN_NFAST")[0] == '0');
     q.tile_rows = env("EVE_FFN_TILE_ROWS") ? atoi(env("EVE_FFN_TILE_ROWS")) : 0;
     q.ksplit = env("EVE_FFN_KSPLIT") ? atoi(env("EVE_FFN_KSPLIT")) : 0;
     return q;
   }();
 #else
-  static const Knobs k = {true, true, true, false, false, true, 0, 0};
+  static const Knobs k = {true, true, true, false, false, true, true, 0, 0};
 #endif
   return k;
 }
@@ -1908,6 +1918,8 @@ int ffn_bwd_mfma(const void* dy, const void* x, const void* z, const void* a, co
   d1.A = (const bf16_t*)dz; d1.a_g = (long)R * I; d1.lda = I;
   d1.B = (const bf16_t*)x; d1.b_g = (long)R * M; d1.ldb = M;
   d1.C = (bf16_t*)dw1; d1.c_g = (long)I * M; d1.ldc = M; d1.N = M; d1.K = R; d1.dbias = (bf16_t*)db1;
+  d.nfast = knobs().nfast && d.Mext > d.N ? 1 : 0;     // (share the larger operand's panel between consecutive tiles)
+  d1.nfast = knobs().nfast && d1.Mext > d1.N ? 1 : 0;
   d.compact = d1.compact = 0;
   if (pp) {
     if (few_unequal_groups(rows, G, E_local)) {  // dynamic slices, see few_unequal_groups
