@@ -363,14 +363,68 @@ template <int PER> __device__ __forceinline__ void wait_tiles_in_flight(int tile
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Eight consecutive columns of one output row, read back from the staging image as two float4 (accumulator + bias),
+// finished two elements at a time on packed fp32 instructions (the activation epilogues are bound by the VALU's
+// instruction issue: in-kernel stamps put the conversions / activation of a half slab at the sum of both SIMD
+// partners' instruction counts x 4 cycles).
+//   MEPI_BIAS_ACT: out2 = a = act(z);  out1 = g = act'(z), what the backward pass needs of z -- saved in its place
+//                  (the `z` tensor of ffn_fwd_mfma), so that the MEPI_DACT epilogue is one multiply per element
+//                  instead of a second sigmoid (exp + rcp + 6 more instructions per element);
+//   MEPI_DACT:     out1 = v * g with g read from the saved tensor (`zw`: eight bf16); `cs` += the unrounded values
+//                  of rows inside the extent (column sums for the bias gradient db1);
+//   otherwise:     out1 = v.
+template <int EPI, int ACT>
+__device__ __forceinline__ void epi_row8(const float4& lo, const float4& hi, const uint4& zw, bool want_g, bool in_extent,
+                                         f32x2_t (&cs)[4], uint4& out1, uint4& out2) {
+  f32x2_t v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+  uint32_t o1[4], o2[4];
+  if constexpr (EPI == MEPI_BIAS_ACT) {
+    if (want_g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2_t a, g;
+        act_fwd_grad2<ACT, true>(v[j], a, g);
+        o1[j] = pack_bf16x2(g.x, g.y);
+        o2[j] = pack_bf16x2(a.x, a.y);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2_t a, g;
+        act_fwd_grad2<ACT, false>(v[j], a, g);
+        o1[j] = 0;
+        o2[j] = pack_bf16x2(a.x, a.y);
+      }
+    }
+  } else {
+    if constexpr (EPI == MEPI_DACT) {
+      const uint32_t* w = &zw.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2_t g = {bf16_bits_to_f32(w[j], 0), bf16_bits_to_f32(w[j], 1)};
+        v[j] = v[j] * g;
+      }
+      if (in_extent) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] = cs[j] + v[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o1[j] = pack_bf16x2(v[j].x, v[j].y); o2[j] = 0; }
+  }
+  out1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+  out2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+}
+
 // Column sums of a wave's output block for the bias gradient (MEPI_DACT): lane (irow = lane >> 3, ich = lane & 7)
 // holds the sums over its rows of columns ncol .. ncol + 7; the eight row lanes are added by a butterfly (fixed
 // order) and the lanes of row lane 0 store the wave's 64 sums as this (group, slot)'s partial.
-__device__ __forceinline__ void colsum_store(float (&cs)[8], const MfmaDesc& d, int z, int slot, int ncol, int lane) {
+__device__ __forceinline__ void colsum_store(const f32x2_t (&cs2)[4], const MfmaDesc& d, int z, int slot, int ncol, int lane) {
   if (!d.colsum) return;
+  float cs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    float v = cs[j];
+    float v = (j & 1) ? cs2[j >> 1].y : cs2[j >> 1].x;
     v += __shfl_xor(v, 8, 64);
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -420,9 +474,9 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
     }
   };
   load_z(0, zbuf[0]);
-  float cs[8];  // DACT: this lane's share of the column sums of the stored values (rows it owns, 8 columns)
+  f32x2_t cs[4];  // DACT: this lane's share of the column sums of the stored values (rows it owns, 8 columns)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  for (int j = 0; j < 4; ++j) cs[j] = f32x2_t{0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     if (i + 1 < WR) load_z(i + 1, zbuf[(i + 1) & 1]);
@@ -452,30 +506,22 @@ __device__ __forceinline__ void tile_epilogue(const acc_tile_t<M16> (&acc)[M16 ?
       const int m = m0 + wm * (WR * 32) + i * 32 + row;
       const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8);
       const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8 + 4);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       const size_t o = (size_t)m * d.ldc + ncol;
-      if constexpr (EPI == MEPI_BIAS_ACT) {
-        if (Cg && m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
-        if (m < mext) *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
-      } else if constexpr (EPI == MEPI_STORE_F32) {
+      if constexpr (EPI == MEPI_STORE_F32) {
         if (m < mext) {  // fp32 partial of a split-K weight gradient; z = split * E_local + expert
           float* o32 = d.Cpart + (size_t)z * d.c_g + o;
           *reinterpret_cast<float4*>(o32) = lo;
           *reinterpret_cast<float4*>(o32 + 4) = hi;
         }
       } else {
-        if constexpr (EPI == MEPI_DACT) {
-          const uint32_t* w = &zbuf[i & 1][it].x;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
-          if (m < mext) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cs[j] += v[j];
-          }
+        uint4 o1, o2;
+        epi_row8<EPI, ACT>(lo, hi, zbuf[i & 1][it], Cg != nullptr, m < mext, cs, o1, o2);
+        if constexpr (EPI == MEPI_BIAS_ACT) {
+          if (Cg && m < mext) *reinterpret_cast<uint4*>(Cg + o) = o1;
+          if (m < mext) *reinterpret_cast<uint4*>(C2g + o) = o2;
+        } else {
+          if (m < mext) *reinterpret_cast<uint4*>(Cg + o) = o1;
         }
-        if (m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1057,7 +1103,22 @@ struct PTile { int which, z, m0, n0, mext, nk, kext; };
 // Epilogue of one wave's 32*WR x 64 outputs through a wave-private [16][EPI_LD] fp32 image.
 template <int EPI, int ACT, int WR>
 __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN], float* ep, const MfmaDesc& d, int z,
-                                                   int e_out, int m0, int n0, int mext, int wave, int lane) {
+                                                   int e_out, int m0, int n0, int mext, int wave, int lane
+#ifdef EVE_PP_STAMP
+                                                   , uint32_t* stamp_e = nullptr  // diagnostic: lane 4q+k = stamp k of half slab q
+#endif
+) {
+#ifdef EVE_PP_STAMP
+#define EVE_ESTAMP(q_, k_)                                                          \
+  do {                                                                             \
+    if (stamp_e) {                                                                 \
+      const uint32_t c_ = (uint32_t)__builtin_amdgcn_s_memtime();                  \
+      *stamp_e = lane == (q_) * 4 + (k_) ? c_ : *stamp_e;                          \
+    }                                                                              \
+  } while (0)
+#else
+#define EVE_ESTAMP(q_, k_) do { } while (0)
+#endif
   const int wm = wave >> 2, wn = wave & 3;
   bf16_t* Cg = d.C ? d.C + (size_t)z * d.c_g : nullptr;
   bf16_t* C2g = d.C2 ? d.C2 + (size_t)z * d.c_g : nullptr;
@@ -1072,25 +1133,59 @@ __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN],
   const int irow = lane >> 3, ich = lane & 7;
   const int ncol = n0 + wn * 64 + ich * 8;
   const int mbase = m0 + wm * (WR * 32);
-  uint4 zbuf[2][2];
+  // Global accesses go through buffer descriptors whose extent is the group's first `mext` rows: a lane whose row
+  // lies beyond it loads zeros and its store is dropped by the hardware.  No exec-masked branch around a store
+  // then -- behind such branches the compiler must assume the stores were NOT issued when it counts vmcnt, and
+  // the wait for a half slab's saved-tensor loads (issued one half slab ahead, with that half slab's stores
+  // between them and the wait) became a wait for those stores' completion: the write latency, about 2 000
+  // cycles, once per half slab (in-kernel stamps, round 3) -- and no 64-bit address arithmetic per access.
+  // (mext comes from rows[], a vector load as far as the compiler knows: readfirstlane keeps the descriptors scalar)
+  const uint32_t ext = (uint32_t)__builtin_amdgcn_readfirstlane(mext) * (uint32_t)d.ldc * 2u;
+  auto group_rsrc = [&](const bf16_t* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, p ? ext : 0u, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t c_rsrc = group_rsrc(Cg), c2_rsrc = group_rsrc(C2g), z_rsrc = group_rsrc(Zg);
+  const uint32_t voff0 = ((uint32_t)(mbase + irow) * (uint32_t)d.ldc + (uint32_t)ncol) * 2u;  // row mbase + irow
+  const uint32_t step8 = 8u * (uint32_t)d.ldc * 2u;                                           // eight rows on
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  // DACT: the saved factors of the wave's whole 32 WR x 64 block are requested before the first store is issued
+  // (16 WR registers, which the K loop's fragments occupy outside the epilogue): they are then ahead of the
+  // tile's stores in the CU's memory pipeline and in the wave's in-order vmcnt queue, and their latency is paid
+  // once per tile beside the first half slab's staging.  Requested a half slab ahead (round 2), each load queued
+  // behind the stores of all eight waves and took 1 500 - 2 500 cycles, once per half slab.
+  uint4 zbuf[EPI == MEPI_DACT ? 2 * WR : 1][2];
   auto load_z = [&](int q, uint4 (&dst)[2]) {  // half slab q: rows mbase + 16 q ..
     if constexpr (EPI == MEPI_DACT) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        const int m = min(mbase + q * 16 + it * 8 + irow, mext - 1);
-        dst[it] = *reinterpret_cast<const uint4*>(Zg + (size_t)m * d.ldc + ncol);
+        const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, voff0 + (uint32_t)(2 * q + it) * step8, 0, 0);
+        dst[it] = make_uint4(w.x, w.y, w.z, w.w);
       }
     }
   };
-  load_z(0, zbuf[0]);
+  auto store8 = [&](const __amdgpu_buffer_rsrc_t& rsrc, const uint4& v, int q, int it) {
+    const u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, voff0 + (uint32_t)(2 * q + it) * step8, 0, 0);
+  };
+  if constexpr (EPI == MEPI_DACT) {
+#pragma unroll
+    for (int q = 0; q < 2 * WR; ++q) load_z(q, zbuf[q]);
+  }
   const int c = lane & 31, hh = lane >> 5;
-  float cs[8];  // DACT: this lane's share of the column sums of the stored values
+  f32x2_t cs[4];  // DACT: this lane's share of the column sums of the stored values
 #pragma unroll
-  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
-#pragma unroll
-  for (int q = 0; q < 2 * WR; ++q) {
+  for (int j = 0; j < 4; ++j) cs[j] = f32x2_t{0.f, 0.f};
+  // The image is private to the wave and the LDS executes one wave's instructions in issue order, so nothing
+  // has to drain between the stores of a half slab and the reads that follow them, nor between those reads and
+  // the stores of the next half slab: the next half slab's stores are issued as soon as this one's reads are,
+  // and their transfer (4 cycles of the VGPR -> LDS path per ds_write_b32) and the reads' latency run beside the
+  // conversions / activation of this half slab instead of in front of them.  (Waiting for lgkmcnt(0) after the
+  // stores and again after the reads, as round 2 did, made a tile's epilogue the SUM of its LDS, VALU and
+  // store-issue time.)
+  auto stage = [&](int q) {
     const int i = q >> 1, hv = q & 1;
-    if (q + 1 < 2 * WR) load_z(q + 1, zbuf[(q + 1) & 1]);
 #pragma unroll
     for (int j = 0; j < WTN; ++j)
 #pragma unroll
@@ -1099,37 +1194,45 @@ __device__ __forceinline__ void tile_epilogue_half(const f32x16 (&acc)[WR][WTN],
         const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh;
         ep[row * EPI_LD + j * 32 + c] = add_bias<EPI>(acc[i][j][r], bv[j]);
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  EVE_ESTAMP(0, 3);  // (bias loaded)
+  stage(0);
+#pragma unroll
+  for (int q = 0; q < 2 * WR; ++q) {
     __builtin_amdgcn_wave_barrier();
+    EVE_ESTAMP(q, 0);
+    float4 lo_[2], hi_[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int row = it * 8 + irow;
-      const int m = mbase + q * 16 + row;
-      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8);
-      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8 + 4);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const size_t o = (size_t)m * d.ldc + ncol;
-      if constexpr (EPI == MEPI_BIAS_ACT) {
-        if (Cg && m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = act_fwd<ACT, true>(v[j]);
-        if (m < mext) *reinterpret_cast<uint4*>(C2g + o) = pack8(v);
-      } else {
-        if constexpr (EPI == MEPI_DACT) {
-          const uint32_t* w = &zbuf[q & 1][it].x;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] *= act_bwd<ACT, true>(bf16_bits_to_f32(w[j >> 1], j & 1));
-          if (m < mext) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cs[j] += v[j];
-          }
-        }
-        if (m < mext) *reinterpret_cast<uint4*>(Cg + o) = pack8(v);
-      }
+      lo_[it] = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8);
+      hi_[it] = *reinterpret_cast<const float4*>(ep + row * EPI_LD + ich * 8 + 4);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if (q + 1 < 2 * WR) stage(q + 1);
+    __builtin_amdgcn_wave_barrier();
+    EVE_ESTAMP(q, 1);  // (the stamp drains lgkmcnt: reads and the next half slab's stores are complete)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      uint4 o1, o2;
+      // (rows beyond the extent: zero accumulators -- the A fetch ends at the extent -- times a zero factor)
+      epi_row8<EPI, ACT>(lo_[it], hi_[it], zbuf[EPI == MEPI_DACT ? q : 0][it], Cg != nullptr, true, cs, o1, o2);
+#ifdef EVE_EXP_NOSTORE  // experiment (diagnostic builds): 1 = no global stores, 2 = only the activation
+      if (EVE_EXP_NOSTORE == 2 && EPI == MEPI_BIAS_ACT) store8(c2_rsrc, o2, q, it);
+      else asm volatile("" :: "v"(o1.x), "v"(o1.y), "v"(o1.z), "v"(o1.w), "v"(o2.x), "v"(o2.y), "v"(o2.z), "v"(o2.w));
+#else
+      if constexpr (EPI == MEPI_BIAS_ACT) {
+        if (Cg) store8(c_rsrc, o1, q, it);  // (uniform: no saved tensor under no_grad)
+        store8(c2_rsrc, o2, q, it);
+      } else {
+        store8(c_rsrc, o1, q, it);
+      }
+#endif
+    }
+    EVE_ESTAMP(q, 2);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the caller reuses or hands on the image)
+  __builtin_amdgcn_wave_barrier();
   if constexpr (EPI == MEPI_DACT) colsum_store(cs, d, z, m0 / (WR * 32) + wm, ncol, lane);
 }
 
@@ -1211,7 +1314,9 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
       f_ostep = (uint32_t)(B_COL ? BKI * d.ldb : BKI) * 2u;
     } else {
       const bf16_t* Ag = d.A + (size_t)ft.z * d.a_g;
-      const uint32_t bytes = (uint32_t)(A_COL ? (WGRAD ? ft.kext : d.K) * d.lda : d.Mext * d.lda) * 2u;
+      // (row-major A: the extent ends at the group's last occupied row, so rows beyond it are fetched as zeros and
+      // their accumulators are exactly zero, whatever the tensor holds there: tile_epilogue_half relies on it)
+      const uint32_t bytes = (uint32_t)(A_COL ? (WGRAD ? ft.kext : d.K) * d.lda : ft.mext * d.lda) * 2u;
       f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ag), 0, bytes, 0x00020000);
       f_voff0 = sub_dma_offset0<A_COL, BKI>(d.lda, w4, lane);
       f_vstride = sub_dma_stride<A_COL>(d.lda);
@@ -1267,7 +1372,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
   // 2 epilogue done, 3 barrier(s) behind the epilogue passed; lanes 62 / 63: kernel start (cycles / 100 MHz ticks).
   // K-step stamps of tile number pr.d[0].same_tile: lane 6t+k of stamp_w, t < 10: k = 0 L start, 1 reads done
   // (lgkmcnt 0), 2 barrier passed, 3 MFMAs issued, 4 fetch landed (vmcnt 0), 5 barrier passed
-  uint32_t stamp_v = 0, stamp_w = 0;
+  uint32_t stamp_v = 0, stamp_w = 0, stamp_e = 0;
   int tile_i = 0;
 #define EVE_KSTAMP(k)                                                              \
   do {                                                                             \
@@ -1385,9 +1490,14 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
       if constexpr (kT)
         tile_epilogue_t<EPI, WR>(acc, reinterpret_cast<char*>(ep), d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0,
                                  cur.n0, cur.mext, wave, lane);
-      else
+      else {
         tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0, cur.n0, cur.mext,
-                                         wave, lane);
+                                         wave, lane
+#ifdef EVE_PP_STAMP
+                                         , tile_i == pr.d[0].same_tile ? &stamp_e : nullptr
+#endif
+        );
+      }
     }
     if constexpr (BIAS_GRAD) {
       if (do_bias_grad) {
@@ -1434,6 +1544,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
   if (pr.d[0].dbg && (blockIdx.x == 0 || blockIdx.x == 100)) {
     pr.d[0].dbg[((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_v;
     pr.d[0].dbg[1024 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_w;
+    pr.d[0].dbg[2048 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + lane] = stamp_e;
   }
 #endif
 #endif  // __HIP_DEVICE_COMPILE__

@@ -198,9 +198,13 @@ enum { EVE_FFN_SHARED_GPU = 1 };
 /* Grouped expert FFN forward.  `x` is [G, R, M]: G groups of R rows; group g is processed
  * by local expert g % E_local (so both the single-GPU layout [E, C, M] and the
  * expert-parallel layout [ep, E_local, C, M] of models/sharded_moe.py:370 are covered).
- *   z = x @ w1[e]^T + b1[e]   [G,R,I]  (saved for backward; NULL = do not store, inference)
+ *   z = x @ w1[e]^T + b1[e]   [G,R,I]  (the `z` buffer is what eve_ffn_bwd needs of it; NULL = do not store, inference)
  *   a = act(z)                [G,R,I]  (saved for backward)
  *   y = a @ w2[e]^T + b2[e]   [G,R,M]
+ * The `z` buffer is OPAQUE to the caller: pass it to eve_ffn_bwd of the same shape and dtype unchanged.  The fp32 path
+ * (and bf16 widths outside the MFMA tiling) stores the pre-activation itself; the bf16 MFMA path stores act'(z), the
+ * only thing the backward pass uses z for (evaluated in the forward epilogue from the sigmoid it computes anyway,
+ * so that the backward epilogue is one multiply per element).
  * w1 [E_local,I,M], b1 [E_local,I], w2 [E_local,M,I], b2 [E_local,M] in `dtype`.
  * rows[g] (may be NULL = R) limits the rows of group g that are computed; rows beyond it
  * are left untouched.  Replaces Experts.forward (models/experts.py:18-28) over

@@ -74,7 +74,7 @@ static void run_p(const char* name, int G, int R, int N, int K, bool bcol, int a
   bf16_t *A, *B, *C, *C2, *bias, *Z;
   unsigned long long* dbg;
   hipMalloc(&A, na * 2); hipMalloc(&B, nb * 2); hipMalloc(&C, nc * 2); hipMalloc(&C2, nc * 2); hipMalloc(&Z, nc * 2); hipMalloc(&bias, (size_t)G * N * 2);
-  hipMalloc(&dbg, 2 * 2 * 8 * 64 * 8);
+  hipMalloc(&dbg, 3 * 2 * 8 * 64 * 8);
   hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice);
   hipMemcpy(B, hb.data(), nb * 2, hipMemcpyHostToDevice);
   hipMemset(bias, 0, (size_t)G * N * 2); hipMemset(Z, 0, nc * 2);
@@ -90,13 +90,13 @@ static void run_p(const char* name, int G, int R, int N, int K, bool bcol, int a
   hipEventRecord(e0, 0);
   for (int i = 0; i < 50; ++i) launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, act, 0, false);
   hipEventRecord(e1, 0);
-  hipMemset(dbg, 0, 2 * 2 * 8 * 64 * 8);
+  hipMemset(dbg, 0, 3 * 2 * 8 * 64 * 8);
   d.dbg = dbg;
   launch_pp<A_COL, B_COL, EPI, WGRAD, BG, BKI, WR>(d, act, 0, false);
   hipDeviceSynchronize();
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  std::vector<unsigned long long> h(2 * 2 * 8 * 64);
+  std::vector<unsigned long long> h(3 * 2 * 8 * 64);
   hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
   auto df = [](unsigned long long x, unsigned long long y) { return (long long)(int)((unsigned)x - (unsigned)y); };
   printf("== persistent %s  G=%d R=%d N=%d K=%d act=%d: %.1f us per launch (%s)\n", name, G, R, N, K, act, ms * 1000 / 50, hipGetErrorString(hipGetLastError()));
@@ -118,6 +118,14 @@ static void run_p(const char* name, int G, int R, int N, int K, bool bcol, int a
           const unsigned long long* q = k + 6 * t;
           if (!q[0]) break;
           printf("     t=%2d  %5lld | %5lld | %5lld | %5lld | %5lld\n", t, df(q[1], q[0]), df(q[2], q[1]), df(q[3], q[2]), df(q[4], q[3]), df(q[5], q[4]));
+        }
+        const unsigned long long* e = &h[2048 + (b * 8 + w) * 64];
+        if (e[0]) {
+          printf("   epilogue of tile %d, per half slab:  reads+next stores issued and landed | conversions, activation, global stores  (first: bias wait %lld)\n", ktile, df(e[3], k[6 * 9 + 5] ? k[6 * 9 + 5] : e[3]));
+          for (int q = 0; q < 8; ++q) {
+            if (!e[4 * q]) break;
+            printf("     q=%d  %5lld | %5lld   [start %lld after q=0]\n", q, df(e[4 * q + 1], e[4 * q]), df(e[4 * q + 2], e[4 * q + 1]), df(e[4 * q], e[0]));
+          }
         }
       }
     }
