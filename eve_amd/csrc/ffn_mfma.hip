@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_pp_wgrad(MfmaPair pr) {
 // phases -- the slot of the finished tile's last B sub-tile, which waves 4-7 refill only in their L'(0),
 // after their own E -- or behind the ring where LDS allows (the 32-deep weight-gradient ring).
 // Single K segment only (weight gradients under expert parallelism use grouped_gemm_pp).
-struct PTile { int which, z, m0, n0, mext, nk, kext; };
+struct PTile { int which, z, e, m0, n0, mext, nk, kext; };  // e: the group's expert
 
 // Epilogue of one wave's 32*WR x 64 outputs through a wave-private [16][EPI_LD] fp32 image.
 template <int EPI, int ACT, int WR>
@@ -1268,42 +1268,72 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
   const unsigned ntotal = (unsigned)pr.ntotal;
   const int np = h == 0 ? NPB : NPA;
 
-  // tile gb of the launch -> its coordinates; false when the block id maps to no work
-  auto decode = [&](unsigned gb, PTile& T) -> bool {
-    const int which = gb >= (unsigned)pr.n0 ? 1 : 0;
-    const MfmaDesc& d = pr.d[which];
-    const unsigned bid = which ? gb - (unsigned)pr.n0 : gb;
-    TileCoord tc;  // (persistent launches never split K: tc.split = 0)
-    if (!tile_of_block<BM, WGRAD, CMP>(d, bid, tc)) return false;
-    const int z = tc.z, m0 = tc.m0, n0 = tc.n0, mext = tc.mext;
-    int kext = d.K;
-    if (WGRAD && d.rows) kext = min(kext, d.rows[z]);  // single segment: group == expert
-    T.which = which; T.z = z; T.m0 = m0; T.n0 = n0; T.mext = mext; T.kext = kext; T.nk = (kext + BKI - 1) / BKI;
+  // ---- tile table.  The workgroup's tiles are gb = blockIdx.x + i * gridDim.x, i < 64 (launch_pp only takes this
+  // kernel when that covers the launch).  Lane i decodes tile i ONCE, here, with vector arithmetic -- gb -> (group,
+  // row tile, column tile) in the XCD-aware order costs half a dozen integer divisions -- and keeps the result in
+  // two registers; both cursors (the tile being multiplied, the tile being fetched) then move on with two
+  // v_readlane each.  Decoding at every move (round 2) put ~1 600 cycles of scalar division into the L phase in
+  // which a cursor crossed a tile boundary, once per tile and half (in-kernel stamps: a K step of 4 100 cycles
+  // instead of 2 400 at t = nk - 3 and again at t = nk - 2), 6 % of a K = 768 tile.
+  //   tt0: bit 0 valid | bit 1 problem | 10 bits column tile | 14 bits group | 6 bits group / E_local
+  //   tt1: 12 bits row tile origin / 64 | 20 bits row extent
+  uint32_t tt0 = 0, tt1 = 0;
+  int ttk = 0;  // weight gradients: K extent (rows of the expert's segment)
+  int n_mine;
+  {
+    const unsigned gb = blockIdx.x + (unsigned)lane * gridDim.x;
+    n_mine = __builtin_popcountll(__ballot(gb < ntotal));
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      if (gb < ntotal && (w == 1) == (gb >= (unsigned)pr.n0)) {
+        const MfmaDesc& d = pr.d[w];
+        TileCoord tc;  // (persistent launches never split K: tc.split = 0)
+        if (tile_of_block<BM, WGRAD, CMP>(d, w ? gb - (unsigned)pr.n0 : gb, tc)) {
+          const int src = WGRAD ? 0 : tc.z / d.E_local;
+          tt0 = 1u | ((uint32_t)w << 1) | ((uint32_t)(tc.n0 / BN) << 2) | ((uint32_t)tc.z << 12) | ((uint32_t)src << 26);
+          tt1 = (uint32_t)(tc.m0 / 64) | ((uint32_t)tc.mext << 12);
+          if (WGRAD) ttk = d.rows ? min(d.K, d.rows[tc.z]) : d.K;  // single segment: group == expert
+        }
+      }
+    }
+  }
+  auto decode = [&](int idx, PTile& T) -> bool {
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)tt0, idx);
+    if (!(a & 1u)) return false;  // the block id maps to no work
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)tt1, idx);
+    T.which = (int)((a >> 1) & 1u);
+    const int e_local = T.which ? pr.d[1].E_local : pr.d[0].E_local, kfull = T.which ? pr.d[1].K : pr.d[0].K;
+    T.n0 = (int)((a >> 2) & 1023u) * BN;
+    T.z = (int)((a >> 12) & 16383u);
+    T.e = WGRAD ? T.z : T.z - (int)(a >> 26) * e_local;
+    T.m0 = (int)(b & 4095u) * 64;
+    T.mext = (int)(b >> 12);
+    T.kext = WGRAD ? __builtin_amdgcn_readlane(ttk, idx) : kfull;
+    T.nk = (T.kext + BKI - 1) / BKI;
     return true;
   };
-  auto advance = [&](unsigned& gb, PTile& T, bool need_k) -> bool {
-    for (gb += gridDim.x; gb < ntotal; gb += gridDim.x)
-      if (decode(gb, T) && (!need_k || T.nk > 0)) return true;
+  auto advance = [&](int& idx, PTile& T, bool need_k) -> bool {
+    for (++idx; idx < n_mine; ++idx)
+      if (decode(__builtin_amdgcn_readfirstlane(idx), T) && (!need_k || T.nk > 0)) return true;
     return false;
   };
 
-  unsigned gb_c = blockIdx.x;
+  int idx_c = -1;
   PTile cur;
-  bool have = gb_c < ntotal;
-  if (have && !decode(gb_c, cur)) have = advance(gb_c, cur, false);
+  bool have = advance(idx_c, cur, false);
   if (!have) return;
 
   // ---- fetch cursor: my operand (waves 0-3: B, waves 4-7: A) of K step t_f of tile ft
-  unsigned gb_f = gb_c;
+  int idx_f = idx_c;
   PTile ft = cur;
   int t_f = 0;
   bool f_valid = true;
-  if (ft.nk == 0) f_valid = advance(gb_f, ft, true);
+  if (ft.nk == 0) f_valid = advance(idx_f, ft, true);
   __amdgpu_buffer_rsrc_t f_rsrc;
   uint32_t f_voff0 = 0, f_vstride = 0, f_origin0 = 0, f_ostep = 0;
   auto set_fetch_desc = [&]() {
     const MfmaDesc& d = pr.d[ft.which];
-    const int e = WGRAD ? ft.z : ft.z % d.E_local;
+    const int e = ft.e;
     if (h == 0) {
       const bf16_t* Bg = d.B + (size_t)(WGRAD ? ft.z : e) * d.b_g;
       const uint32_t bytes = (uint32_t)(B_COL ? (WGRAD ? ft.kext : d.K) * d.ldb : d.N * d.ldb) * 2u;
@@ -1336,7 +1366,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
                                                  16, f_voff0 + (origin + (uint32_t)i * f_vstride), 0, 0, 0);
     if (++t_f == ft.nk) {
       t_f = 0;
-      f_valid = advance(gb_f, ft, true);
+      f_valid = advance(idx_f, ft, true);
       if (f_valid) set_fetch_desc();
     }
   };
@@ -1488,11 +1518,9 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
       }
     } else {
       if constexpr (kT)
-        tile_epilogue_t<EPI, WR>(acc, reinterpret_cast<char*>(ep), d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0,
-                                 cur.n0, cur.mext, wave, lane);
+        tile_epilogue_t<EPI, WR>(acc, reinterpret_cast<char*>(ep), d, cur.z, cur.e, cur.m0, cur.n0, cur.mext, wave, lane);
       else {
-        tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, WGRAD ? cur.z : cur.z % d.E_local, cur.m0, cur.n0, cur.mext,
-                                         wave, lane
+        tile_epilogue_half<EPI, ACT, WR>(acc, ep, d, cur.z, cur.e, cur.m0, cur.n0, cur.mext, wave, lane
 #ifdef EVE_PP_STAMP
                                          , tile_i == pr.d[0].same_tile ? &stamp_e : nullptr
 #endif
@@ -1522,7 +1550,7 @@ __global__ __launch_bounds__(512) void grouped_gemm_ppp(MfmaPair pr) {
       for (int j = 0; j < WTN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    have = advance(gb_c, cur, false);
+    have = advance(idx_c, cur, false);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my staging image is free again
     EVE_PSTAMP(2);
     // waves 4-7 run one phase behind: their last E phase has no partner phase and no barrier
@@ -1812,8 +1840,14 @@ static int launch_pp(const MfmaDesc& d, int act, hipStream_t st, bool shared, co
   // epilogues run it with resynchronised E phases (kResync; EVE_FFN_PERSIST_ACT=0 selects the one-tile kernel
   // for A/B timing: the persistent one measured 2 % faster on those launches).
   const bool act_epi = EPI == MEPI_BIAS_ACT || EPI == MEPI_DACT;
+  // (the persistent kernel keeps its tiles in a 64-entry per-lane table with packed fields, see grouped_gemm_ppp)
+  const int pgrid = (cu_count() / 8) * 8;
+  auto packs = [](const MfmaDesc& q) {
+    return q.G < 16384 && q.G / q.E_local <= 64 && q.N / BN < 1024 && q.Mext <= 262144;
+  };
   const bool persist = use_persistent(shared) && (!act_epi || knobs().persist_act) &&
-                       EPI != MEPI_STORE_F32 && (!WGRAD || d.G == d.E_local) && pr.ntotal > cu_count();
+                       EPI != MEPI_STORE_F32 && (!WGRAD || d.G == d.E_local) && pr.ntotal > cu_count() &&
+                       pr.ntotal <= 64 * pgrid && packs(pr.d[0]) && packs(pr.d[1]);
   constexpr int kStage = 8 * 16 * EPI_LD * 4;
   constexpr int kLdsP = (5 * 256 * BKI * 2 + kStage > 160 * 1024) ? 5 * 256 * BKI * 2 : 5 * 256 * BKI * 2 + kStage;
   dim3 grid(persist ? (cu_count() / 8) * 8 : pr.ntotal);
