@@ -60,6 +60,7 @@ st, sq, fe, wr = stats("trace"), pmc("pmc_sq"), pmc("pmc_fetch"), pmc("pmc_write
 gemm_flops = 2.0 * M * I * K
 alg = {  # kernel -> (algorithmic bytes, flops, note)
     "gate_logits_mfma_kernel": (S * M * b + 4 * S * E, 2.0 * S * M * E, "S*M*b + 4*S*E"),
+    "gate_logits_walk_kernel": (S * M * b + 4 * S * E, 2.0 * S * M * E, "S*M*b + 4*S*E"),
     "gate_select32_kernel": (12 * E * S, 0, "logits + draws in, gates out: 12E B/token"),
     "gate_assign32_kernel": (40 * S, 0, "idx/rank in, loc/slot/weight + slot maps out"),
     "dispatch_fwd_kernel": ((S + K) * M * b, 0, "(S+K)*M*b"),

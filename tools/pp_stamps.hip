@@ -132,7 +132,63 @@ static void run_p(const char* name, int G, int R, int N, int K, bool bcol, int a
   hipFree(A); hipFree(B); hipFree(C); hipFree(C2); hipFree(Z); hipFree(bias); hipFree(dbg);
 }
 
+// the production weight-gradient launch (grouped_gemm_pp_wgrad: one tile per workgroup, both dW GEMMs): K-step
+// timeline of two workgroups
+static void run_w(int G, int R, int M, int I) {
+  const size_t ndy = (size_t)G * R * M, na = (size_t)G * R * I;
+  std::vector<unsigned short> h1(ndy), h2(na);
+  srand(1);
+  for (auto& v : h1) v = 0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15);
+  for (auto& v : h2) v = 0x3a00 + (rand() & 0x3ff) + ((rand() & 1) << 15);
+  bf16_t *dy, *x, *a, *dz, *dw1, *dw2;
+  unsigned long long* dbg;
+  hipMalloc(&dy, ndy * 2); hipMalloc(&x, ndy * 2); hipMalloc(&a, na * 2); hipMalloc(&dz, na * 2);
+  hipMalloc(&dw1, (size_t)G * M * I * 2); hipMalloc(&dw2, (size_t)G * M * I * 2);
+  hipMalloc(&dbg, 2 * 8 * 64 * 8);
+  hipMemcpy(dy, h1.data(), ndy * 2, hipMemcpyHostToDevice); hipMemcpy(x, h1.data(), ndy * 2, hipMemcpyHostToDevice);
+  hipMemcpy(a, h2.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dz, h2.data(), na * 2, hipMemcpyHostToDevice);
+  MfmaDesc d{};
+  d.G = G; d.E_local = G; d.rows = nullptr;
+  d.Mext = M; d.A = dy; d.a_g = (long)R * M; d.lda = M; d.B = a; d.b_g = (long)R * I; d.ldb = I;
+  d.C = dw2; d.c_g = (long)M * I; d.ldc = I; d.N = I; d.K = R;
+  MfmaDesc d1 = d;
+  d1.Mext = I; d1.A = dz; d1.a_g = (long)R * I; d1.lda = I; d1.B = x; d1.b_g = (long)R * M; d1.ldb = M;
+  d1.C = dw1; d1.c_g = (long)I * M; d1.ldc = M; d1.N = M; d1.K = R;
+  d.nfast = d.Mext > d.N; d1.nfast = d1.Mext > d1.N;
+  d.dbg = d1.dbg = nullptr;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 100; ++i) launch_pp_wgrad<MEPI_STORE>(d, d1, 0, true);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < 30; ++i) launch_pp_wgrad<MEPI_STORE>(d, d1, 0, true);
+  hipEventRecord(e1, 0);
+  hipMemset(dbg, 0, 2 * 8 * 64 * 8);
+  d.dbg = d1.dbg = dbg;
+  launch_pp_wgrad<MEPI_STORE>(d, d1, 0, true);
+  hipDeviceSynchronize();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(2 * 8 * 64);
+  hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+  auto df = [](unsigned long long p, unsigned long long q) { return (long long)(int)((unsigned)p - (unsigned)q); };
+  printf("== weight gradients (one tile per workgroup) G=%d R=%d M=%d I=%d: %.1f us per launch (%s)\n", G, R, M, I, ms * 1000 / 30, hipGetErrorString(hipGetLastError()));
+  for (int b = 0; b < 2; ++b)
+    for (int w = 0; w < 8; w += 4) {
+      const unsigned long long* q = &h[(b * 8 + w) * 64];
+      printf(" block %d wave %d: start -> first L %lld | K loop %lld | epilogue + store drain %lld | whole %lld\n", b ? 1000 : 0, w, df(q[0], q[62]),
+             df(q[60], q[0]), df(q[61], q[60]), df(q[61], q[62]));
+      for (int t = 0; t < 10; ++t) {
+        const unsigned long long* k = q + 6 * t;
+        const unsigned long long* n = k + 6;
+        if (!k[0]) break;
+        printf("     t=%2d  L %5lld | %5lld | M %5lld | vmcnt %5lld | %5lld\n", t, df(k[1], k[0]), df(k[2], k[1]), df(k[3], k[2]), df(k[4], k[3]),
+               t < 9 ? df(n[0], k[4]) : 0LL);
+      }
+    }
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'w') { run_w(32, 948, 768, 3072); return 0; }
   if (argc > 2) {  // "p <nwg>": fc1 with half the groups on <nwg> workgroups -- the same work per CU, fewer CUs storing
     g_stamp_grid = atoi(argv[2]);
     run_p<false, false, MEPI_BIAS_ACT, false, false, 64>("fwd1 bias+act, G=32 on the override grid", 32, 948, 3072, 768, false, EVE_ACT_QUICK_GELU);
