@@ -43,7 +43,7 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_bwd(float z) 
 // packed forms halve the issue time of the GEMM epilogues, which are bound by it): forward activation `a` and the
 // derivative `g` = act'(z) from ONE sigmoid.  The MFMA expert-FFN kernels save g (not z) for the backward pass,
 // whose epilogue is then a multiply: with t = z * (-1.702 log2 e), s = 1 / (1 + 2^t):
-//   a = z s,   g = s (1 + 1.702 z (1 - s)) = s (1 - ln 2 * t (1 - s)).
+//   a = z s,   g = s (1 + 1.702 z (1 - s)) = s + 1.702 (a - a s).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <int ACT, bool WANT_G>
 __device__ __forceinline__ void act_fwd_grad2(f32x2_t z, f32x2_t& a, f32x2_t& g) {
@@ -58,9 +58,8 @@ __device__ __forceinline__ void act_fwd_grad2(f32x2_t z, f32x2_t& a, f32x2_t& g)
     s.y = __builtin_amdgcn_rcpf(d.y);
     a = z * s;
     if constexpr (WANT_G) {
-      const f32x2_t w = t * (1.f - s);
-      const f32x2_t k = {-0.69314718056f, -0.69314718056f}, one = {1.f, 1.f};
-      g = s * __builtin_elementwise_fma(w, k, one);
+      const f32x2_t k = {1.702f, 1.702f};
+      g = __builtin_elementwise_fma(k, a - a * s, s);  // s (1 + 1.702 z (1 - s)) with z s = a
     }
   } else {
     a.x = act_fwd<ACT, true>(z.x);

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 9
+#define EVE_MOE_ABI_VERSION 10
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
