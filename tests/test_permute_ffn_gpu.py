@@ -86,12 +86,18 @@ def test_dispatch_and_combine_roundtrip(dtype, B, T, n_vis, M, E, mode):
         torch.testing.assert_close(dt.cpu().double(), rt, rtol=1e-4, atol=1e-3)
 
 
-def _ffn_ref(x, w1, b1, w2, b2, rows, E_l):
+_ACT_REF = {"gelu": torch.nn.functional.gelu, "relu": torch.relu, "identity": lambda t: t}
+
+
+def _ffn_ref(x, w1, b1, w2, b2, rows, E_l, act="quick_gelu"):
     G, R, M = x.shape
     ys = []
     for g in range(G):
         e = g % E_l
-        ys.append(orc.expert_ffn(x[g], w1[e], b1[e], w2[e], b2[e]))
+        if act == "quick_gelu":
+            ys.append(orc.expert_ffn(x[g], w1[e], b1[e], w2[e], b2[e]))
+        else:  # the other ACT2FN choices of models/multiway_transformer.py:47, straight from torch
+            ys.append(_ACT_REF[act](x[g] @ w1[e].T + b1[e]) @ w2[e].T + b2[e])
     return torch.stack(ys)
 
 
@@ -100,7 +106,7 @@ def _ffn_ref(x, w1, b1, w2, b2, rows, E_l):
                                                   (32, 32, 119, 768, 3072, True), (6, 2, 130, 256, 512, True),
                                                   (1, 1, 300, 256, 512, False), (4, 2, 700, 256, 256, True),
                                                   (2, 2, 1024, 512, 256, False), (8, 4, 474, 256, 768, True)])
-def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
+def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows, act="quick_gelu"):
     from eve_amd import ops
     g = torch.Generator().manual_seed(G * R + M)
     x = torch.randn(G, R, M, generator=g)
@@ -120,12 +126,12 @@ def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
     if rows is not None:
         mask = (torch.arange(R)[None, :, None] < rows[:, None, None]).double()
     leaves = [t.double().requires_grad_(True) for t in (xs, w1s, b1s, w2s, b2s)]
-    yref = _ffn_ref(*leaves, rows, E_l)
+    yref = _ffn_ref(*leaves, rows, E_l, act)
     (yref * dys.double() * mask).sum().backward()
 
     d = lambda t: t.to(DEV) if t is not None else None
-    z, a, y = ops.ffn_fwd(d(xs), d(w1s), d(b1s), d(w2s), d(b2s), d(rows), ops.ACTS["quick_gelu"])
-    dx, dw1, db1, dw2, db2 = ops.ffn_bwd(d(dys), d(xs), z, a, d(w1s), d(w2s), d(rows), ops.ACTS["quick_gelu"])
+    z, a, y = ops.ffn_fwd(d(xs), d(w1s), d(b1s), d(w2s), d(b2s), d(rows), ops.ACTS[act])
+    dx, dw1, db1, dw2, db2 = ops.ffn_bwd(d(dys), d(xs), z, a, d(w1s), d(w2s), d(rows), ops.ACTS[act])
     torch.cuda.synchronize()
     m3 = mask.bool().expand(G, R, M)
     tol = TOL[dtype]
@@ -139,6 +145,15 @@ def test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, use_rows):
         if dtype == torch.bfloat16:  # and element by element: rtol 2e-2 + 4 % of the tensor's rms (see tests/test_layer_gpu.py)
             from tests.helpers import assert_close_scaled
             assert_close_scaled(got, ref, 2e-2, 4e-2, name)
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu", "identity"])
+@pytest.mark.parametrize("dtype,G,E_l,R,M,I", [(torch.float32, 4, 2, 33, 64, 128), (torch.bfloat16, 6, 2, 300, 256, 512),
+                                               (torch.bfloat16, 3, 3, 130, 512, 256)])
+def test_grouped_ffn_other_activations(act, dtype, G, E_l, R, M, I):
+    """ACT2FN's other choices (models/multiway_transformer.py:47; EVE's configs use quick_gelu): the bf16 MFMA path
+    saves act'(z) in the forward epilogue for every activation, not only for the one the benchmarks run."""
+    test_grouped_ffn_fwd_bwd(dtype, G, E_l, R, M, I, True, act)
 
 
 @pytest.mark.parametrize("G,E_l,R,M,I,use_rows", [
