@@ -127,6 +127,12 @@ __device__ __forceinline__ int token_modality(int s, int T, int n_vis, int mode)
 }
 
 // permute.hip: the closing stage of the fused backward (eve_moe_bwd), eve_route_bwd + eve_gate_wgrad in two launches
+bool combine_gate_bwd_fusable(const void* dout, const void* y, const int32_t* slot, const void* dy, const int32_t* idx,
+                              const int32_t* loc, int M, int E, int dtype);
+int combine_bwd_gate_bwd(const void* dout, const void* y, const int32_t* slot, const int32_t* slot_token, const float* slot_weight,
+                         void* dy, float* d_weight, const float* gates, const int32_t* idx, const int32_t* loc,
+                         const float* d_l_aux, const int64_t* exp_counts, float* dlogits, int S, int M, int E, int C,
+                         int num_slots, int dtype, void* stream);
 bool route_wgrad_fusable(const void* dxd, const int32_t* slot, const void* dh, const void* h, int M, int E, int dtype);
 int route_bwd_gate_wgrad(const void* dxd, const int32_t* slot, const float* dlogits, const float* wg, void* dh, void* dvision,
                          void* dtext, const void* h, const void* vision_embed, const void* text_embed, float* dwg, int S, int T,

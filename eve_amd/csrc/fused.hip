@@ -215,10 +215,20 @@ extern "C" int eve_moe_bwd(const eve_moe_shape* p, const void* dout, const float
   float* dlogits = reinterpret_cast<float*>(w + ws.off[WS_DLOGITS]);
   float* dweight = reinterpret_cast<float*>(w + ws.off[WS_DWEIGHT]);
   const int n = p->E * p->C;
-  if (int rc = eve_combine_bwd(dout, y, slot, slot_token, slot_weight, dy, dweight, p->S, p->M, n, p->dtype, stream)) return rc;
+  // (the gate's backward needs nothing but d weight: where the shapes allow, the combine backward forms d logits in
+  // the same launch instead of a 5 us launch of its own between the expert GEMMs and the route backward)
+  const bool gate_in_combine = combine_gate_bwd_fusable(dout, y, slot, dy, idx, loc, p->M, p->E, p->dtype);
+  if (gate_in_combine) {
+    if (int rc = combine_bwd_gate_bwd(dout, y, slot, slot_token, slot_weight, dy, dweight, gates, idx, loc, d_l_aux, exp_counts,
+                                      dlogits, p->S, p->M, p->E, p->C, n, p->dtype, stream)) return rc;
+  } else {
+    if (int rc = eve_combine_bwd(dout, y, slot, slot_token, slot_weight, dy, dweight, p->S, p->M, n, p->dtype, stream)) return rc;
+  }
   if (int rc = eve_ffn_bwd(dy, xd, z, a, w1, w2, dz, dxd, dw1, db1, dw2, db2, rows, p->E, p->E, p->C, p->M, p->I, p->act, p->dtype, 0,
                            w + ws.off[WS_FFN], eve_ffn_bwd_workspace_bytes(p->E, p->E, p->C, p->M, p->I, p->dtype), stream)) return rc;
-  if (int rc = eve_gate_top2_bwd(gates, idx, loc, dweight, d_l_aux, exp_counts, p->S, p->E, p->C, dlogits, stream)) return rc;
+  if (!gate_in_combine) {
+    if (int rc = eve_gate_top2_bwd(gates, idx, loc, dweight, d_l_aux, exp_counts, p->S, p->E, p->C, dlogits, stream)) return rc;
+  }
   const bool want_v = dvision && (p->mode == EVE_MODE_VL || p->mode == EVE_MODE_VISION);
   const bool want_t = dtext && (p->mode == EVE_MODE_VL || p->mode == EVE_MODE_TEXT);
   // route backward and gate weight gradient are independent of each other: one launch for both, one for their closing

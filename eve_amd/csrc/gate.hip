@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "gate_bwd32.h"
 #include "gate_wgrad_bf16.h"
 
 namespace eve {
@@ -632,28 +633,9 @@ __global__ __launch_bounds__(256) void gate_bwd32_kernel(const float* __restrict
     const float g = valid ? gates[(size_t)sc * E + ec] : 0.f;
     const int i1 = idx[2 * sc], i2 = idx[2 * sc + 1];
     const bool k1 = loc[2 * sc] < C, k2 = loc[2 * sc + 1] < C;
-    const float gi1 = __shfl(g, tk * 32 + i1, 64), gi2 = __shfl(g, tk * 32 + i2, 64);
-    const float g1 = k1 ? gi1 : 0.f, g2 = k2 ? gi2 : 0.f;
     const float dw1 = d_weight ? d_weight[2 * sc] : 0.f, dw2 = d_weight ? d_weight[2 * sc + 1] : 0.f;
-    const float sum = g1 + g2;
-    float dg1, dg2;
-    if (sum >= kEps) {  // clamp inactive: w_k = g_k / (g1 + g2)
-      const float inv2 = 1.f / (sum * sum);
-      dg1 = (dw1 - dw2) * g2 * inv2;
-      dg2 = (dw2 - dw1) * g1 * inv2;
-    } else {  // clamp active: w_k = g_k / eps
-      dg1 = dw1 / kEps;
-      dg2 = dw2 / kEps;
-    }
-    if (!k1) dg1 = 0.f;
-    if (!k2) dg2 = 0.f;
-    float dg = aux;
-    if (e == i1) dg += dg1;
-    if (e == i2) dg += dg2;
-    float dot = g * dg;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
-    if (valid) dlogits[(size_t)s * E + e] = g * (dg - dot);
+    const float dl_e = gate_bwd32_token(g, i1, i2, k1, k2, dw1, dw2, aux, e, tk);
+    if (valid) dlogits[(size_t)s * E + e] = dl_e;
   }
 }
 

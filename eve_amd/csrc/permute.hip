@@ -2,6 +2,7 @@
 // one-hot einsums (models/sharded_moe.py:367 and :377) and their autograd backward, plus the
 // modality-embedding gradient.  HBM-bound row movers: one wave per row, 16 B per lane.
 #include "common.h"
+#include "gate_bwd32.h"
 #include "gate_wgrad_bf16.h"
 
 namespace eve {
@@ -310,16 +311,30 @@ __global__ __launch_bounds__(256) void combine_fwd_np_kernel(const T* __restrict
   }
 }
 
-template <typename T, int NP>
+// (d weight, d l_aux -> d logits of the token, E <= 32: what the fused backward passes so that the gate's backward
+// needs no launch of its own; gates == nullptr when the kernel is instantiated without it)
+struct GateBwdArgs {
+  const float* gates; const int32_t* idx; const int32_t* loc; const float* d_l_aux; const int64_t* exp_counts;
+  float* dlogits; int E, C;
+};
+
+template <typename T, int NP, bool GB = false>
 __global__ __launch_bounds__(256) void combine_bwd_np_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                              const int32_t* __restrict__ slot,
                                                              const int32_t* __restrict__ slot_token,
                                                              const float* __restrict__ slot_weight, T* __restrict__ dy,
-                                                             float* __restrict__ d_weight, int S, int num_slots) {
+                                                             float* __restrict__ d_weight, int S, int num_slots,
+                                                             GateBwdArgs gb) {
   constexpr int N = Vec16<T>::N, M = 32 * NP * N;
   const int lane = lane_id(), l32 = lane & 31, half = lane >> 5;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  // GB: the gate's backward for the token, in the same half wave with lane = expert (gate_bwd32.h)
+  float aux = 0.f;
+  if constexpr (GB) {
+    const float dl = gb.d_l_aux ? gb.d_l_aux[0] : 0.f;
+    aux = dl * (float)gb.E / ((float)S * (float)S) * (float)gb.exp_counts[min(l32, gb.E - 1)];
+  }
   for (int s0 = 2 * wave; s0 < S; s0 += 2 * nwaves) {
     const int s = min(s0 + half, S - 1);
     const bool live = s0 + half < S;
@@ -336,6 +351,14 @@ __global__ __launch_bounds__(256) void combine_bwd_np_kernel(const T* __restrict
       v2[p] = load16<T>(y2 + (p * 32 + l32) * N);
     }
     const float w1 = s1 >= 0 ? slot_weight[s1] : 0.f, w2 = s2 >= 0 ? slot_weight[s2] : 0.f;
+    // (GB: the token's gate row and choices, requested with the rows so that the tail does not wait for them)
+    float gate_g = 0.f;
+    int2 gate_ix = make_int2(0, 0), gate_lc = make_int2(0, 0);
+    if constexpr (GB) {
+      gate_g = live && l32 < gb.E ? gb.gates[(size_t)s * gb.E + min(l32, gb.E - 1)] : 0.f;
+      gate_ix = *reinterpret_cast<const int2*>(gb.idx + 2 * s);
+      gate_lc = *reinterpret_cast<const int2*>(gb.loc + 2 * s);
+    }
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -362,6 +385,12 @@ __global__ __launch_bounds__(256) void combine_bwd_np_kernel(const T* __restrict
     if (l32 == 0 && live) {
       d_weight[2 * s] = s1 >= 0 ? a1 : 0.f;
       d_weight[2 * s + 1] = s2 >= 0 ? a2 : 0.f;
+    }
+    if constexpr (GB) {
+      const int e = l32, E = gb.E;
+      const float dl_e = gate_bwd32_token(gate_g, gate_ix.x, gate_ix.y, gate_lc.x < gb.C, gate_lc.y < gb.C, s1 >= 0 ? a1 : 0.f,
+                                          s2 >= 0 ? a2 : 0.f, aux, e, half);
+      if (live && e < E) gb.dlogits[(size_t)s * E + e] = dl_e;
     }
   }
   for (int base = wave * 64; base < num_slots; base += nwaves * 64) {  // empty slots
@@ -883,6 +912,18 @@ using namespace eve;
     }                                                                                             \
   } while (0)
 
+#define EVE_LAUNCH_NP_GB(KERNEL, TT, np, grid, st, ...)                                                \
+  do {                                                                                                 \
+    switch (np) {                                                                                      \
+      case 1: hipLaunchKernelGGL((KERNEL<TT, 1, true>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+      case 2: hipLaunchKernelGGL((KERNEL<TT, 2, true>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+      case 3: hipLaunchKernelGGL((KERNEL<TT, 3, true>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+      case 4: hipLaunchKernelGGL((KERNEL<TT, 4, true>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+      case 6: hipLaunchKernelGGL((KERNEL<TT, 6, true>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+      default: hipLaunchKernelGGL((KERNEL<TT, 8, true>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+    }                                                                                                  \
+  } while (0)
+
 #define EVE_DISPATCH_DTYPE(dtype, KERNEL, grid, block, st, ...)                                     \
   do {                                                                                              \
     if ((dtype) == EVE_F32) hipLaunchKernelGGL((KERNEL<float>), grid, block, 0, st, __VA_ARGS__);   \
@@ -978,10 +1019,10 @@ extern "C" int eve_combine_bwd(const void* dout, const void* y, const int32_t* s
   if (np && aligned_to(slot, 8) && aligned_to(dout, 16) && aligned_to(y, 16) && aligned_to(dy, 16)) {
     if (dtype == EVE_F32)
       EVE_LAUNCH_NP(combine_bwd_np_kernel, float, np, dim3(pair_grid(S)), st, (const float*)dout, (const float*)y, slot,
-                    slot_token, slot_weight, (float*)dy, d_weight, S, num_slots);
+                    slot_token, slot_weight, (float*)dy, d_weight, S, num_slots, GateBwdArgs{});
     else
       EVE_LAUNCH_NP(combine_bwd_np_kernel, bf16_t, np, dim3(pair_grid(S)), st, (const bf16_t*)dout, (const bf16_t*)y, slot,
-                    slot_token, slot_weight, (bf16_t*)dy, d_weight, S, num_slots);
+                    slot_token, slot_weight, (bf16_t*)dy, d_weight, S, num_slots, GateBwdArgs{});
     EVE_CHECK_LAUNCH("combine_bwd_np_kernel");
     return EVE_OK;
   }
@@ -995,6 +1036,40 @@ extern "C" int eve_combine_bwd(const void* dout, const void* y, const int32_t* s
   EVE_CHECK_LAUNCH("combine_bwd_kernel");
   return EVE_OK;
 }
+
+// eve_combine_bwd + eve_gate_top2_bwd as ONE launch (the fused backward, fused.hip): the half wave that forms a
+// token's d weight goes on to its d logits, lane = expert (gate_bwd32.h: the function gate_bwd32_kernel runs, so the
+// result is bit-identical to the two calls).  The gate's backward depends on nothing but d weight; as a launch of its
+// own it sat between the expert GEMMs and the route backward, 5 us of latency for 2 MB.  `combine_gate_bwd_fusable`:
+// the shapes that take the row-mover kernel and the 32-expert gate kernel.
+namespace eve {
+bool combine_gate_bwd_fusable(const void* dout, const void* y, const int32_t* slot, const void* dy, const int32_t* idx,
+                              const int32_t* loc, int M, int E, int dtype) {
+  return E <= 32 && row_passes(M, dtype) != 0 && aligned_to(slot, 8) && aligned_to(dout, 16) && aligned_to(y, 16) &&
+         aligned_to(dy, 16) && aligned_to(idx, 8) && aligned_to(loc, 8);
+}
+
+int combine_bwd_gate_bwd(const void* dout, const void* y, const int32_t* slot, const int32_t* slot_token, const float* slot_weight,
+                         void* dy, float* d_weight, const float* gates, const int32_t* idx, const int32_t* loc,
+                         const float* d_l_aux, const int64_t* exp_counts, float* dlogits, int S, int M, int E, int C,
+                         int num_slots, int dtype, void* stream) {
+  EVE_REQUIRE(dout && y && slot && slot_token && slot_weight && dy && d_weight && gates && idx && loc && exp_counts && dlogits,
+              EVE_ERR_ARG, "eve_moe_bwd (combine + gate backward): null pointer");
+  EVE_REQUIRE(S > 0 && num_slots > 0 && E > 0 && E <= 32 && C > 0, EVE_ERR_ARG, "eve_moe_bwd (combine + gate backward): bad shape");
+  const int np = row_passes(M, dtype);
+  EVE_REQUIRE(np != 0, EVE_ERR_UNSUPPORTED, "eve_moe_bwd (combine + gate backward): width %d", M);
+  hipStream_t st = S_(stream);
+  const GateBwdArgs gb{gates, idx, loc, d_l_aux, exp_counts, dlogits, E, C};
+  if (dtype == EVE_F32)
+    EVE_LAUNCH_NP_GB(combine_bwd_np_kernel, float, np, dim3(pair_grid(S)), st, (const float*)dout, (const float*)y, slot,
+                     slot_token, slot_weight, (float*)dy, d_weight, S, num_slots, gb);
+  else
+    EVE_LAUNCH_NP_GB(combine_bwd_np_kernel, bf16_t, np, dim3(pair_grid(S)), st, (const bf16_t*)dout, (const bf16_t*)y, slot,
+                     slot_token, slot_weight, (bf16_t*)dy, d_weight, S, num_slots, gb);
+  EVE_CHECK_LAUNCH("combine_bwd_np_kernel (with the gate backward)");
+  return EVE_OK;
+}
+}  // namespace eve
 
 static const int kEmbedTS = 32;
 
