@@ -384,6 +384,22 @@ class _CombineFn(torch.autograd.Function):
         return dy, dw, None, None, None
 
 
+class _DispatchFn(torch.autograd.Function):
+    """x [S,M] (modality embedding already added) -> dispatched [E*C,M]: the einsum 'sec,sm->ecm' of reference
+    sharded_moe.py:367 on its own, for the path whose gate input differs from what is dispatched (Jitter)."""
+
+    @staticmethod
+    def forward(ctx, x2d, slot, slot_token):  # type: ignore[override]
+        ctx.save_for_backward(slot)
+        ctx.S = x2d.shape[0]
+        return ops.dispatch_fwd(x2d.contiguous(), None, None, slot_token, 1, 0, _lib.MODE_NONE, slot=slot)
+
+    @staticmethod
+    def backward(ctx, dxd):  # type: ignore[override]
+        (slot,) = ctx.saved_tensors
+        return ops.dispatch_bwd(dxd.contiguous(), slot, None, None, ctx.S), None, None
+
+
 def _cast(t: Optional[Tensor], dtype: torch.dtype) -> Optional[Tensor]:
     """`t.to(dtype).contiguous()` of a (small) parameter, made anew on every call like the per-stage path makes it.
     Round 2 kept the copy per (tensor, version counter, storage pointer); an update through `.data` -- what older
@@ -842,6 +858,33 @@ class MOELayer(nn.Module):
         out = _EPFinishFn.apply(y.reshape(E * C, M), weight, blob, key)
         return out.view(orig_shape)
 
+    def _forward_jitter(self, h, orig_shape, vemb, temb, noise, is_uniform, n_vis, code, E, jitter):
+        """noisy_gate_policy='Jitter' in training (reference sharded_moe.py:290-291 inside :345-381): the logits come
+        from `multiplicative_jitter(x.float())`, x = h + modality embedding, while x itself is dispatched."""
+        B, T, M = h.shape
+        S = B * T
+        gate = self.gate
+        if code == _lib.MODE_VL:
+            x = torch.cat([h[:, :n_vis] + vemb, h[:, n_vis:] + temb], dim=1)
+        elif code == _lib.MODE_VISION:
+            x = h + vemb
+        elif code == _lib.MODE_TEXT:
+            x = h + temb
+        else:
+            x = h
+        x2d = x.to(h.dtype).reshape(S, M).contiguous()
+        logits = _LogitsFn.apply((x2d.float() * jitter).contiguous(), gate.wg.weight)
+        C = ops.capacity(S, E, gate.active_capacity_factor(), gate.min_capacity)
+        weight, l_aux, slot, slot_token, slot_weight, rows, exp_counts, _, _ = _GateFn.apply(logits, noise, C, is_uniform)
+        self.l_aux = l_aux
+        self.exp_counts = self._host_counts(exp_counts)
+        self.last_slot = slot
+        xd = _DispatchFn.apply(x2d, slot, slot_token)
+        dispatched = xd.view(1, self.num_local_experts, C, M)
+        y = self.experts(dispatched, rows=rows) if _accepts_rows(self.experts) else self.experts(dispatched)
+        out = _CombineFn.apply(y.reshape(E * C, M), weight, slot, slot_token, slot_weight)
+        return out.view(orig_shape)
+
     def forward(self, *input: Tensor, mode='vl', **kwargs: Any) -> Tensor:
         h = input[0]
         if not h.is_cuda:
@@ -867,15 +910,22 @@ class MOELayer(nn.Module):
         else:
             vemb_in = temb_in = None
         E = gate.num_experts if hasattr(gate, "num_experts") else gate.wg.weight.shape[0]
+        jitter = None
+        if gate.noisy_gate_policy == 'Jitter' and self.training:
+            # (drawn before the Gumbel noise, as the reference's gate does, :290-293: same generator consumption)
+            jitter = multiplicative_jitter(torch.ones(S, M, dtype=torch.float32, device=h.device), device=h.device)
         noise = self.noise_override
         self.noise_override = None
         is_uniform = False
         if noise is None:
             noise, is_uniform = _draw_noise((S, E), h.device)
-        if gate.noisy_gate_policy == 'Jitter' and self.training:
-            raise NotImplementedError("eve_amd.MOELayer: noisy_gate_policy='Jitter' is not used by EVE and is only "
-                                      "supported through TopKGate.forward")
         n_vis = int(self.num_vision_tokens) if has_embed else 0
+        if gate.noisy_gate_policy == 'Jitter' and self.training:
+            # never set by EVE; the gate then sees a jittered copy of what is dispatched (reference :290-291), so the
+            # fused route / dispatch calls (one input for both) do not apply: stage by stage, single rank only
+            if self.ep_size > 1:
+                raise NotImplementedError("eve_amd.MOELayer: noisy_gate_policy='Jitter' with expert parallelism")
+            return self._forward_jitter(h, orig_shape, vemb, temb, noise, is_uniform, n_vis, code, E, jitter)
 
         if (self.ep_size == 1 and self.fused_call and not self.split_call and not ops.PROFILE.on
                 and getattr(self.experts, "packed_parameters", None) is not None and E == self.num_local_experts

@@ -241,11 +241,15 @@ def expert_ffn(x: torch.Tensor, w1, b1, w2, b2) -> torch.Tensor:
 
 # -------------------------------------------------------------------- dense layer (port)
 def dense_moe_forward(h: torch.Tensor, p: Dict[str, torch.Tensor], noise: torch.Tensor, *, mode: str = "vl",
-                      n_vis: Optional[int] = None, capacity_factor: float = 1.0, min_capacity: int = 4):
+                      n_vis: Optional[int] = None, capacity_factor: float = 1.0, min_capacity: int = 4,
+                      jitter: Optional[torch.Tensor] = None):
     """The layer as the reference executes it (one-hot einsums + per-expert loop):
-    sharded_moe.py:345-381 + experts.py:18-28.  Returns (out, l_aux, exp_counts)."""
+    sharded_moe.py:345-381 + experts.py:18-28.  Returns (out, l_aux, exp_counts).
+    `jitter` [S,M]: the factors of multiplicative_jitter (sharded_moe.py:46-67) under noisy_gate_policy='Jitter' in
+    training: the gate's Linear sees x.float() * jitter (:290-292); what is dispatched stays x."""
     x = modality_input(h, p, mode, n_vis)
-    logits = x.float() @ p["wg"].float().t()
+    gate_in = x.float() if jitter is None else x.float() * jitter
+    logits = gate_in @ p["wg"].float().t()
     l_aux, combine, mask, exp_counts = dense_top2gating(logits, noise, capacity_factor, min_capacity)
     E = p["wg"].shape[0]
     slots = torch.einsum("sec,sm->ecm", mask.to(h.dtype), x)

@@ -263,3 +263,54 @@ def test_activation_checkpoint_recompute_replays_the_gumbel_draw(use_reentrant):
     assert torch.equal(s_a[0], s_b[0])
     assert torch.equal(out_a, out_b) and torch.equal(dh_a, dh_b)
     assert all(torch.equal(a, b) for a, b in zip(g_a, g_b))
+
+
+@pytest.mark.parametrize("mode", ["vl", "vision", "plain"])
+def test_jitter_gate_policy_matches_the_oracle(mode, monkeypatch):
+    """noisy_gate_policy='Jitter' in training (reference sharded_moe.py:290-291; never set by EVE): the gate's Linear
+    sees x * U[1-eps, 1+eps), what is dispatched stays x.  No reference golden holds this policy ("parity unpinned"
+    against the reference itself: its jitter is drawn on the device inside the gate); checked against the oracle's
+    restatement with the SAME factors injected, output and every gradient, and against the routing without the
+    factors (which must differ: they are drawn wide enough here to move logits)."""
+    import eve_amd.sharded_moe as sm
+    M, I, E, B, n_vis, T = 64, 128, 32, 6, 9, 15
+    p = orc.make_params(M, I, E, seed=41)
+    h = orc.synth_hidden(B, T, M, seed=42)
+    g = torch.Generator().manual_seed(43)
+    noise = orc.gumbel_noise((B * T, E), generator=g)
+    dout = torch.randn(B, T, M, generator=g)
+    fac = 1.0 + 0.6 * (torch.rand(B * T, M, generator=g) - 0.5)
+    monkeypatch.setattr(sm, "multiplicative_jitter", lambda x, device, epsilon=1e-2: x * fac.to(x.device))
+    nv = None if mode == "plain" else n_vis
+    omode = "vl" if mode == "plain" else mode
+    moe = build_moe(p, M, I, E, nv, device=DEV, noisy_gate_policy="Jitter").train()
+    hd = h.to(DEV).requires_grad_(True)
+    moe.moe.noise_override = noise.to(DEV)
+    out, l_aux, cnt = moe(hd, mode=omode)
+    ((out * dout.to(DEV)).sum() + 0.7 * l_aux).backward()
+    torch.cuda.synchronize()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    hr = h.clone().requires_grad_(True)
+    ro, rl, rc = orc.dense_moe_forward(hr, pr, noise, mode=omode, n_vis=nv, jitter=fac)
+    ((ro * dout).sum() + 0.7 * rl).backward()
+    with torch.no_grad():
+        _, _, plain_counts = orc.dense_moe_forward(h, p, noise, mode=omode, n_vis=nv)
+    assert torch.equal(cnt, rc)
+    assert not torch.equal(cnt, plain_counts)
+    assert_fp32_close(out, ro, "out")
+    np.testing.assert_allclose(l_aux.item(), rl.item(), rtol=1e-5)
+    assert_fp32_close(hd.grad, hr.grad, "dh")
+    assert_fp32_close(moe.moe.gate.wg.weight.grad, pr["wg"].grad, "dwg")
+    if nv:
+        for pname in ("vision_embed", "text_embed"):
+            got, ref = getattr(moe.moe, pname).grad, pr[pname].grad
+            zero = torch.zeros(M)
+            assert_fp32_close(zero if got is None else got, zero if ref is None else ref, "d" + pname)
+    for got, name in zip(expert_grads(moe, E), ("w1", "b1", "w2", "b2")):
+        assert_fp32_close(got, pr[name].grad, "d" + name)
+    # eval: the policy is a training-time one, the layer must then equal the jitter-free layer
+    moe.eval()
+    moe.moe.noise_override = noise.to(DEV)
+    with torch.no_grad():
+        oe, _, ce = moe(h.to(DEV), mode=omode)
+    assert torch.equal(ce, plain_counts)
