@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3/4/5 and 12-layer encoder entries")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a HIP graph")
+    ap.add_argument("--torch-noise", action="store_true",
+                    help="draw the gate's Gumbel noise from torch's device generator (a torch.rand kernel per step, and "
+                         "torch's generator bookkeeping before every graph replay) instead of inside the gate kernel "
+                         "from a device-resident Philox state (eve_amd.DeviceNoise)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--allow-foreign-lib", action="store_true",
                     help="run although EVE_MOE_LIB selects another library than eve_amd/libeve_moe.so (kernel A/B "
@@ -102,6 +106,9 @@ def self_launch(args) -> int:
 
 
 # ------------------------------------------------------------------------------------------ workload
+DEVICE_NOISE = True  # main(): False under --torch-noise
+
+
 def build_layer(M, I, E, ep, rank, n_vis, dtype, dev):
     """One modality-aware MoE layer with independent experts, initialised on the GPU."""
     import eve_amd
@@ -123,6 +130,8 @@ def build_layer(M, I, E, ep, rank, n_vis, dtype, dev):
     # exp_counts as an asynchronous pinned copy (opt-in; the default is the reference's blocking .to('cpu')):
     # a timed step must not contain a host synchronisation per layer
     moe.moe.blocking_exp_counts = False
+    if DEVICE_NOISE:  # fresh Gumbel noise every step either way; here the gate kernel draws it (eve_amd.DeviceNoise)
+        moe.set_noise_source("device", seed=777 + rank)
     return moe
 
 
@@ -422,6 +431,8 @@ def main():
                          "unset it, or pass --allow-foreign-lib for an A/B experiment (the line then says so)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    global DEVICE_NOISE
+    DEVICE_NOISE = not args.torch_noise
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -467,7 +478,9 @@ def main():
     use_graph = world == 1 and not args.no_graph
     if use_graph:
         import eve_amd
+        moe.moe.track_last_slot = False  # the diagnostic copy of the routing map is not part of a training step
         graphed = eve_amd.GraphedTrainStep(moe, h, dout, mode="vl")
+        moe.moe.track_last_slot = True   # (the eager profile steps below read it for the kept-row count)
         # h / dout are resident in the graph's input buffers (graphed.static_h / static_dout), as when the
         # producing layer writes them in place; the eager path reads them in place as well
         step = lambda: graphed()
@@ -547,6 +560,8 @@ def main():
                                    f"capacity_factor 1.0, mode vl", "tokens_per_gpu": S, "kept_assignments": kept,
                        "parallelism": f"ep{world}" if world > 1 else "single",
                        "launch": "hipgraph replay of the whole step" if use_graph else "eager, one launch per kernel",
+                       "gumbel_noise": ("fresh every step, drawn inside the gate kernel from a device-resident Philox4x32-10 state"
+                                        if DEVICE_NOISE else "fresh every step, torch.rand on torch's device generator"),
                        "library_source_hash": _lib.source_hash()},
             "roofline": roofline,
             "roofline_hbm": hbm_rooflines(prof, args.steps, S, kept, M, E, 2 if args.dtype == "bf16" else 4),

@@ -15,8 +15,8 @@ from .graph import GraphedTrainStep
 from .layer import MoE
 from .multiway import ModalitySplitFFN
 from . import retrieval
-from .sharded_moe import MOELayer, TopKGate, gumbel_rsample, top2gating
+from .sharded_moe import DeviceNoise, MOELayer, TopKGate, gumbel_rsample, top2gating
 
-__all__ = ["Attention", "MultiwayTransformerEncoder", "MultiwayTransformerEncoderLayer", "MultiwayTransformerEnocderLayer",
+__all__ = ["Attention", "DeviceNoise", "MultiwayTransformerEncoder", "MultiwayTransformerEncoderLayer", "MultiwayTransformerEnocderLayer",
            "eve_base_encoder", "MoE", "GraphedTrainStep", "ModalitySplitFFN", "MOELayer", "TopKGate", "Experts", "MultiwayTransformerMLP", "QuickGELU", "ACT2FN",
            "gumbel_rsample", "top2gating", "retrieval"]

@@ -89,6 +89,37 @@ __device__ __forceinline__ float gumbel_of_uniform(float r) {
   return __fadd_rn(0.f, __fmul_rn(-1.f, logf(a)));
 }
 
+// ---- noise source 2: the gate draws its own standard-uniform values --------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; the generator family behind curand / torch's device generator), keyed by the
+// 64-bit seed, counter = offset + (element >> 2) in words 0/1 (words 2/3 zero), element = s * E + e of the [S,E]
+// noise tensor, value = word (element & 3) of the block; uniform = (word >> 8) * 2^-24 in [0,1).  `noise` then
+// points at the 16-byte device state {seed, offset} (include/eve_moe.h), read here and advanced by
+// ceil(S * E / 4) in the kernel that follows the selection (gate_assign32_kernel / gate_scan_kernel).
+constexpr int kNoisePhilox = 2;
+struct Philox4 { unsigned w[4]; };
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long ctr, unsigned long long seed) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ float philox_unit(unsigned w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+__device__ __forceinline__ float philox_uniform_at(const unsigned long long* st, unsigned long long element) {
+  const Philox4 b = philox4x32_10(st[1] + (element >> 2), st[0]);
+  const unsigned k = (unsigned)element & 3u;
+  return philox_unit(k == 0 ? b.w[0] : k == 1 ? b.w[1] : k == 2 ? b.w[2] : b.w[3]);
+}
+// (thread 0 of block 0 of the kernel after the selection; a vector store)
+__device__ __forceinline__ void philox_advance(unsigned long long* st, unsigned long long inc) {
+  if (st && blockIdx.x == 0 && threadIdx.x == 0) st[1] += inc;
+}
+
 // Pass 1 (select): one thread per token.  softmax, first / second choice, rank of the token
 // among earlier tokens OF ITS BLOCK with the same choice (wave ballots + LDS), per-block
 // histograms and per-block column sums of the gates.  Also clears slot_token.
@@ -117,7 +148,7 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
   const bool live = s < S;
   const int lane = lane_id();
   const float* row = logits + (size_t)(live ? s : 0) * E;
-  const float* nrow = noise + (size_t)(live ? s : 0) * E;
+  const float* nrow = noise + (noise_is_uniform == kNoisePhilox ? 0 : (size_t)(live ? s : 0) * E);
   float* grow = gates + (size_t)(live ? s : 0) * E;
 
   // softmax exactly as exp(x - max) / sum; first choice = argmax of the GATES (ties -> lowest e);
@@ -138,7 +169,10 @@ __global__ __launch_bounds__(kGateBlock) void gate_select_kernel(
   float best2 = -INFINITY;
   for (int e = 0; e < E; ++e) {
     if (e == i1) continue;
-    const float v = row[e] + (noise_is_uniform ? gumbel_of_uniform(nrow[e]) : nrow[e]);
+    const float nv = noise_is_uniform == kNoisePhilox
+                         ? philox_uniform_at(reinterpret_cast<const unsigned long long*>(noise), (unsigned long long)(live ? s : 0) * E + e)
+                         : nrow[e];
+    const float v = row[e] + (noise_is_uniform ? gumbel_of_uniform(nv) : nv);
     if (i2 < 0 || v > best2) { best2 = v; i2 = e; }
   }
   if (i2 < 0) i2 = 0;  // E == 1: masked_fill leaves all -inf, argmax -> 0
@@ -222,18 +256,28 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
     const bool live = s < S;
     const int e0 = q * 8;
     float x[8], nz[8];
+    const bool own_draws = noise_is_uniform == kNoisePhilox;
+    const unsigned long long* rng = reinterpret_cast<const unsigned long long*>(noise);
     if (E32) {
       const float4* lp = reinterpret_cast<const float4*>(logits + (size_t)(live ? s : 0) * 32 + e0);
-      const float4* np = reinterpret_cast<const float4*>(noise + (size_t)(live ? s : 0) * 32 + e0);
-      const float4 a = lp[0], b = lp[1], c = np[0], d = np[1];
+      const float4 a = lp[0], b = lp[1];
       x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
-      nz[0] = c.x, nz[1] = c.y, nz[2] = c.z, nz[3] = c.w, nz[4] = d.x, nz[5] = d.y, nz[6] = d.z, nz[7] = d.w;
+      if (own_draws) {  // the lane's eight elements are two whole Philox blocks
+        const unsigned long long c0 = rng[1] + ((unsigned long long)(live ? s : 0) * 32 + e0) / 4;
+        const Philox4 p = philox4x32_10(c0, rng[0]), r = philox4x32_10(c0 + 1, rng[0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nz[j] = philox_unit(p.w[j]), nz[4 + j] = philox_unit(r.w[j]);
+      } else {
+        const float4* np = reinterpret_cast<const float4*>(noise + (size_t)(live ? s : 0) * 32 + e0);
+        const float4 c = np[0], d = np[1];
+        nz[0] = c.x, nz[1] = c.y, nz[2] = c.z, nz[3] = c.w, nz[4] = d.x, nz[5] = d.y, nz[6] = d.z, nz[7] = d.w;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const size_t o = (size_t)(live ? s : 0) * E + min(e0 + j, E - 1);
         x[j] = logits[o];
-        nz[j] = noise[o];
+        nz[j] = own_draws ? philox_uniform_at(rng, o) : noise[o];
       }
     }
     bool valid[8];
@@ -334,8 +378,11 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
 __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restrict__ hist, int32_t* __restrict__ boff,
                                                         const float* __restrict__ gsum, int32_t* __restrict__ tot,
                                                         int64_t* __restrict__ exp_counts, int32_t* __restrict__ rows,
-                                                        float* __restrict__ l_aux, int S, int E, int C, int nblk) {
+                                                        float* __restrict__ l_aux, int S, int E, int C, int nblk,
+                                                        unsigned long long* __restrict__ rng_state,
+                                                        unsigned long long rng_inc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  philox_advance(rng_state, rng_inc);
   int32_t* stot = reinterpret_cast<int32_t*>(smem);   // [2E]
   float* sme = reinterpret_cast<float*>(stot + 2 * E);  // [E]
   const int lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -480,8 +527,9 @@ __global__ __launch_bounds__(512) void gate_assign32_kernel(
     const int32_t* __restrict__ hist, const float* __restrict__ gsum, int S, int E, int C, int32_t* __restrict__ loc,
     int32_t* __restrict__ slot, float* __restrict__ weight, int32_t* __restrict__ slot_token,
     float* __restrict__ slot_weight, int64_t* __restrict__ exp_counts, int32_t* __restrict__ rows,
-    float* __restrict__ l_aux) {
+    float* __restrict__ l_aux, unsigned long long* __restrict__ rng_state, unsigned long long rng_inc) {
   __shared__ int32_t pbefore[8][64], pall[8][64];
+  philox_advance(rng_state, rng_inc);
   __shared__ int32_t pre[64], tot[64];
   __shared__ float gpart[16][32];
   __shared__ float term[32];
@@ -1196,6 +1244,10 @@ static int gate_top2_launch(const float* logits, const float* noise, int noise_i
   float* gsum = reinterpret_cast<float*>(ws + w.gsum);
   int32_t* tot = reinterpret_cast<int32_t*>(ws + w.tot);
   const int fused_assign = E <= 32 && w.nblk <= kAssign32MaxBlocks ? 1 : 0;
+  // noise source 2: `noise` is the device generator state; the kernel after the selection advances it
+  unsigned long long* rng_state = noise_is_uniform == kNoisePhilox
+                                      ? reinterpret_cast<unsigned long long*>(const_cast<float*>(noise)) : nullptr;
+  const unsigned long long rng_inc = ((unsigned long long)S * E + 3) / 4;
   if (E <= 32) {
     if (E == 32)
       hipLaunchKernelGGL(gate_select32_kernel<true>, dim3(w.nblk), dim3(256), 0, st, logits, noise, noise_is_uniform, S, E,
@@ -1213,13 +1265,13 @@ static int gate_top2_launch(const float* logits, const float* noise, int noise_i
   }
   if (fused_assign) {
     hipLaunchKernelGGL(gate_assign32_kernel, dim3(w.nblk), dim3(512), 0, st, gates, idx, rank, hist, gsum, S, E, C, loc,
-                       slot, weight, slot_token, slot_weight, exp_counts, rows, l_aux);
+                       slot, weight, slot_token, slot_weight, exp_counts, rows, l_aux, rng_state, rng_inc);
     EVE_CHECK_LAUNCH("gate_assign32_kernel");
     return EVE_OK;
   }
   const size_t lds2 = (size_t)4 * E * 4;
   hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(1024), lds2, st, hist, boff, gsum, tot, exp_counts, rows, l_aux, S,
-                     E, C, w.nblk);
+                     E, C, w.nblk, rng_state, rng_inc);
   EVE_CHECK_LAUNCH("gate_scan_kernel");
   hipLaunchKernelGGL(gate_assign_kernel, dim3(w.nblk), dim3(kGateBlock), 0, st, gates, idx, rank, boff, tot, S, E, C,
                      loc, slot, weight, slot_token, slot_weight);
@@ -1232,6 +1284,10 @@ static int gate_top2_launch(const float* logits, const float* noise, int noise_i
                   rows && l_aux,                                                                                       \
               EVE_ERR_ARG, who ": null pointer");                                                                      \
   EVE_REQUIRE(S > 0 && E > 0 && C > 0, EVE_ERR_ARG, who ": bad shape S=%d E=%d C=%d", S, E, C);                        \
+  EVE_REQUIRE(noise_is_uniform >= 0 && noise_is_uniform <= 2, EVE_ERR_ARG, who ": noise_is_uniform=%d (0, 1 or 2)",    \
+              noise_is_uniform);                                                                                       \
+  EVE_REQUIRE(noise_is_uniform != 2 || ((uintptr_t)noise & 7) == 0, EVE_ERR_ARG,                                       \
+              who ": the generator state (noise_is_uniform == 2) must be 8-byte aligned");                             \
   EVE_REQUIRE(E <= 1024, EVE_ERR_UNSUPPORTED, who ": E=%d > 1024", E);                                                 \
   EVE_REQUIRE((long long)E * C < (1ll << 31), EVE_ERR_ARG, who ": E*C overflows int32")
 

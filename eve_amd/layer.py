@@ -63,6 +63,11 @@ class MoE(torch.nn.Module):
         when ep_size equals the world size."""
         self.moe._set_ep_group(group)
 
+    def set_noise_source(self, source: str = "torch", seed=None) -> None:
+        """Where the gate's Gumbel noise comes from: torch's device generator (default, the reference's behaviour)
+        or a generator state on the device that the gate kernel draws from itself (`eve_amd.DeviceNoise`)."""
+        self.moe.set_noise_source(source, seed)
+
     def forward(self, hidden_states, **kwargs):
         """-> (output, l_aux, exp_counts); `mode='vl'|'vision'|'text'` selects the modality routing."""
         routed = self.moe(hidden_states, **kwargs)

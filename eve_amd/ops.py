@@ -132,11 +132,33 @@ def gumbel_from_uniform(u: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int, noise_is_uniform: bool = False) -> Routing:
-    """`noise`: Gumbel variates [S,E], or (noise_is_uniform) the torch.rand draws they are made of."""
-    _chk(logits, "logits", torch.float32), _chk(noise, "noise", torch.float32)
+NOISE_GUMBEL, NOISE_UNIFORM, NOISE_DEVICE_PHILOX = 0, 1, 2  # include/eve_moe.h: values of noise_is_uniform
+
+
+def noise_code(noise: torch.Tensor, noise_is_uniform, S: int, E: int) -> int:
+    """The `noise_is_uniform` argument of the C calls for (noise, flag) -- False / True / NOISE_DEVICE_PHILOX -- after
+    checking that `noise` is what that value says: an fp32 [S,E] tensor, or the int64 {seed, offset} generator state
+    the gate kernel draws from and advances (`eve_amd.DeviceNoise.state`)."""
+    code = int(noise_is_uniform)
+    if code == NOISE_DEVICE_PHILOX:
+        _chk(noise, "generator state", torch.int64)
+        if noise.numel() != 2:
+            raise ValueError("eve_amd: the device generator state is an int64 tensor {seed, offset}")
+        return code
+    if code not in (NOISE_GUMBEL, NOISE_UNIFORM):
+        raise ValueError(f"eve_amd: noise_is_uniform={noise_is_uniform!r}")
+    _chk(noise, "noise", torch.float32)
+    if tuple(noise.shape) != (S, E):
+        raise RuntimeError("eve_amd: gate parameter / noise shapes do not match the layer input")
+    return code
+
+
+def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int, noise_is_uniform=False) -> Routing:
+    """`noise`: Gumbel variates [S,E], or (noise_is_uniform) the torch.rand draws they are made of, or
+    (noise_is_uniform == NOISE_DEVICE_PHILOX) the device generator state the kernel draws from itself."""
+    _chk(logits, "logits", torch.float32)
     S, E = logits.shape
-    assert noise.shape == logits.shape
+    code = noise_code(noise, noise_is_uniform, S, E)
     dev = logits.device
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
@@ -146,7 +168,7 @@ def gate_top2(logits: torch.Tensor, noise: torch.Tensor, C: int, noise_is_unifor
                 torch.empty(1, **f32))
     nbytes = _lib.load().eve_gate_workspace_bytes(S, E)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    PROFILE.call("eve_gate_top2_fwd", _p(logits), _p(noise), 1 if noise_is_uniform else 0, S, E, C, _p(r.gates), _p(r.idx), _p(r.loc), _p(r.slot),
+    PROFILE.call("eve_gate_top2_fwd", _p(logits), _p(noise), code, S, E, C, _p(r.gates), _p(r.idx), _p(r.loc), _p(r.slot),
               _p(r.weight), _p(r.slot_token), _p(r.slot_weight), _p(r.exp_counts), _p(r.rows), _p(r.l_aux), _p(ws),
               nbytes, _stream())
     return r

@@ -87,10 +87,38 @@ def gumbel_rsample(shape, device: torch.device) -> Tensor:
 _own_gumbel_rsample = gumbel_rsample
 
 
-def _draw_noise(shape, device: torch.device) -> Tuple[Tensor, bool]:
+class DeviceNoise:
+    """A device-resident Philox4x32-10 generator state {seed, offset} (int64[2]) from which the gate kernel draws the
+    uniform values of its Gumbel noise ITSELF (include/eve_moe.h, EVE_NOISE_DEVICE_PHILOX) and which it advances on
+    the stream: no noise tensor, no draw kernel, no host work per step -- and, inside a HIP graph, none of the
+    generator bookkeeping torch runs before every replay of a graph that holds a `torch.rand` (two fill kernels and
+    a launch gap, ~25 us per step at the cfg-2 shape).  Stands for the draw of reference sharded_moe.py:186 where
+    torch's generator STREAM is not needed; the values are not torch's, so `torch.manual_seed` does not steer them
+    and torch's RNG stashing (activation checkpointing) does not rewind them -- use `snapshot()` / `restore()`."""
+
+    _instances = 0
+
+    def __init__(self, device, seed: Optional[int] = None) -> None:
+        if seed is None:  # a distinct stream per instance, reproducible under torch.manual_seed
+            seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (DeviceNoise._instances + 1)) % (1 << 64)
+        DeviceNoise._instances += 1
+        seed = int(seed) % (1 << 64)
+        self.state = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, 0], dtype=torch.int64, device=device)
+
+    def snapshot(self) -> Tensor:
+        return self.state.clone()
+
+    def restore(self, snap: Tensor) -> None:
+        self.state.copy_(snap)
+
+
+def _draw_noise(shape, device: torch.device, source: Optional[DeviceNoise] = None) -> Tuple[Tensor, int]:
     """(noise, is_uniform) for the gate kernel: the torch.rand draw itself when the kernel may apply the
     Gumbel transform (the same generator consumption as `gumbel_rsample`), else finished Gumbel variates
-    -- also when a caller has replaced this module's `gumbel_rsample`, as the goldens' scripts do."""
+    -- also when a caller has replaced this module's `gumbel_rsample`, as the goldens' scripts do.  With a
+    `DeviceNoise` source: its state, for the kernel to draw from (nothing is drawn here)."""
+    if source is not None:
+        return source.state, ops.NOISE_DEVICE_PHILOX
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
@@ -455,9 +483,10 @@ class _FusedMoEFn(torch.autograd.Function):
         E, I = wg32.shape[0], w1.shape[1]
         for t, n in ((w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (ve, "vision_embed"), (te, "text_embed")):
             ops._chk(t, n, h.dtype)
-        ops._chk(h2d, "hidden"), ops._chk(wg32, "wg", torch.float32), ops._chk(noise, "noise", torch.float32)
+        ops._chk(h2d, "hidden"), ops._chk(wg32, "wg", torch.float32)
+        ncode = ops.noise_code(noise, noise_is_uniform, S, E)
         if w1.shape != (E, I, M) or w2.shape != (E, M, I) or b1.shape != (E, I) or b2.shape != (E, M) \
-                or noise.shape != (S, E) or wg32.shape[1] != M:
+                or wg32.shape[1] != M:
             raise RuntimeError("eve_amd: expert / gate parameter shapes do not match the layer input")
         C = ops.capacity(S, E, cap_factor, min_capacity)
         v_dt = None if vemb is None else vemb.dtype
@@ -476,7 +505,7 @@ class _FusedMoEFn(torch.autograd.Function):
         out = torch.empty(B, T, M, dtype=h.dtype, device=dev)
         l_aux = torch.empty((), dtype=torch.float32, device=dev)
         ops.PROFILE.call("eve_moe_fwd", ref, ops._p(h2d), ops._p(ve), ops._p(te), ops._p(wg32), ops._p(noise),
-                         1 if noise_is_uniform else 0, ops._p(w1), ops._p(b1), ops._p(w2), ops._p(b2), ops._p(out),
+                         ncode, ops._p(w1), ops._p(b1), ops._p(w2), ops._p(b2), ops._p(out),
                          ops._p(l_aux), ops._p(blob), nbytes, 1 if need_bwd else 0, ops._p(ws), nws, ops._stream())
         o = offs["slot"]
         slot = blob[o:o + S * 8].view(torch.int32).view(S, 2)
@@ -544,10 +573,11 @@ class _EPRouteFn(torch.autograd.Function):
         wg32 = _cast(wg, torch.float32)
         ve, te = _cast(vemb, h.dtype), _cast(temb, h.dtype)
         noise = noise.contiguous()
-        ops._chk(h2d, "hidden"), ops._chk(wg32, "wg", torch.float32), ops._chk(noise, "noise", torch.float32)
+        ops._chk(h2d, "hidden"), ops._chk(wg32, "wg", torch.float32)
+        ncode = ops.noise_code(noise, noise_is_uniform, S, E)
         ops._chk(ve, "vision_embed", h.dtype), ops._chk(te, "text_embed", h.dtype)
-        if noise.shape != (S, E) or tuple(wg32.shape) != (E, M):
-            raise RuntimeError("eve_amd: gate parameter / noise shapes do not match the layer input")
+        if tuple(wg32.shape) != (E, M):
+            raise RuntimeError("eve_amd: gate parameter shapes do not match the layer input")
         v_dt = None if vemb is None else vemb.dtype
         t_dt = None if temb is None else temb.dtype
         fused_dt = torch.bfloat16 if key[10] == _lib.BF16 else torch.float32
@@ -560,7 +590,7 @@ class _EPRouteFn(torch.autograd.Function):
         xd = torch.empty(E * C, M, dtype=h.dtype, device=dev)
         l_aux = torch.empty((), dtype=torch.float32, device=dev)
         ops.PROFILE.call("eve_moe_route_fwd", ref, ops._p(h2d), ops._p(ve), ops._p(te), ops._p(wg32), ops._p(noise),
-                         1 if noise_is_uniform else 0, ops._p(xd), ops._p(l_aux), ops._p(blob), nbytes, ops._p(ws), nws,
+                         ncode, ops._p(xd), ops._p(l_aux), ops._p(blob), nbytes, ops._p(ws), nws,
                          ops._stream())
         view = lambda name, n, dt: blob[offs[name]:offs[name] + n].view(dt)
         weight = view("weight", S * 8, torch.float32).view(S, 2)
@@ -773,6 +803,10 @@ class MOELayer(nn.Module):
         self.l_aux = None
         self.exp_counts = None
         self.noise_override: Optional[Tensor] = None  # tests: replaces the Gumbel draw once
+        # `last_slot` ([S,2] token -> slot map of the latest forward, diagnostics) is a COPY on the fused paths (their
+        # map lives in the saved-state blob); False skips that copy (one ~5 us copy node of a captured step)
+        self.track_last_slot = True
+        self.device_noise: Optional[DeviceNoise] = None  # set_noise_source("device"): the gate draws its own noise
 
         self.num_vision_tokens = None
         if num_tokens:
@@ -781,6 +815,18 @@ class MOELayer(nn.Module):
             self.text_embed = nn.Parameter(torch.zeros(self.gate.model_dim))
             trunc_normal_(self.text_embed, std=0.02)
             self.num_vision_tokens = num_tokens
+
+    def set_noise_source(self, source: str = "torch", seed: Optional[int] = None, device=None) -> None:
+        """"torch" (default): the Gumbel draw consumes torch's device generator exactly as the reference's
+        `gumbel_rsample` does (sharded_moe.py:70-77).  "device": the gate kernel draws from a `DeviceNoise` state of
+        this layer (see there for what that changes)."""
+        if source == "torch":
+            self.device_noise = None
+        elif source == "device":
+            dev = device if device is not None else self.gate.wg.weight.device
+            self.device_noise = DeviceNoise(dev, seed)
+        else:
+            raise ValueError("eve_amd.MOELayer.set_noise_source: 'torch' or 'device'")
 
     def _host_counts(self, exp_counts: Tensor) -> Tensor:
         if torch.cuda.is_current_stream_capturing():
@@ -836,7 +882,7 @@ class MOELayer(nn.Module):
         blob = holder["blob"]
         self.l_aux = l_aux
         self.exp_counts = self._host_counts(exp_counts)
-        self.last_slot = slot.clone()
+        self.last_slot = slot.clone() if self.track_last_slot else None
         group = self._resolve_ep_group()
         w1, b1, w2, b2 = self.experts.packed_parameters(xd.dtype)
         ep, e_l = self.ep_size, self.num_local_experts
@@ -918,7 +964,7 @@ class MOELayer(nn.Module):
         self.noise_override = None
         is_uniform = False
         if noise is None:
-            noise, is_uniform = _draw_noise((S, E), h.device)
+            noise, is_uniform = _draw_noise((S, E), h.device, self.device_noise)
         n_vis = int(self.num_vision_tokens) if has_embed else 0
         if gate.noisy_gate_policy == 'Jitter' and self.training:
             # never set by EVE; the gate then sees a jittered copy of what is dispatched (reference :290-291), so the
@@ -939,7 +985,7 @@ class MOELayer(nn.Module):
             self.exp_counts = self._host_counts(exp_counts)
             # a copy (S * 8 bytes): a view would keep the whole `saved` blob (xd, z, a, y: ~0.5 GB at the cfg-2 shape)
             # alive on the module after backward, until this layer's next forward
-            self.last_slot = slot.clone()
+            self.last_slot = slot.clone() if self.track_last_slot else None
             return out.view(orig_shape)
 
         packed = getattr(self.experts, "packed_parameters", None) is not None

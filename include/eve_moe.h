@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_MOE_ABI_VERSION 10
+#define EVE_MOE_ABI_VERSION 11
 
 enum { EVE_F32 = 0, EVE_BF16 = 1 };
 
@@ -93,10 +93,19 @@ size_t eve_gate_workspace_bytes(int S, int E);
  *                     only ones that can be occupied
  *   l_aux      [1]    load-balance loss                                       (:202-204)
  * `noise` holds the Gumbel variates themselves (noise_is_uniform == 0) or the standard-uniform draws in
- * [0,1) they are made of (noise_is_uniform != 0; transformed inside the kernel with the arithmetic of
- * eve_gumbel_from_uniform, bit for bit).  slot_weight needs no clearing by the caller.
+ * [0,1) they are made of (noise_is_uniform == 1; transformed inside the kernel with the arithmetic of
+ * eve_gumbel_from_uniform, bit for bit).  noise_is_uniform == 2 (EVE_NOISE_DEVICE_PHILOX, since ABI 11): the
+ * gate draws the uniform values itself and `noise` points at a 16-byte, 8-byte-aligned device generator state
+ * `uint64_t {seed, offset}` instead of a tensor: element s*E+e of the (never materialised) [S,E] draw is word
+ * (s*E+e) & 3 of Philox4x32-10 keyed by `seed` at counter `offset + ((s*E+e) >> 2)` (counter words 2, 3 zero),
+ * mapped to [0,1) as (word >> 8) * 2^-24 and then transformed as above; the call ADVANCES `offset` by
+ * ceil(S*E/4) on the stream (so the state is written although the parameter is const-qualified), which makes
+ * consecutive calls -- and replays of a HIP graph that holds the call -- draw fresh noise with no host work.
+ * It stands for the draw of models/sharded_moe.py:186 when the caller does not need torch's generator stream.
+ * slot_weight needs no clearing by the caller.
  * Routing indices and drops are bit-exact w.r.t. the reference for identical
  * (logits, noise); fp outputs agree to fp32 rounding.  Deterministic (no atomics). */
+enum { EVE_NOISE_GUMBEL = 0, EVE_NOISE_UNIFORM = 1, EVE_NOISE_DEVICE_PHILOX = 2 };  /* values of noise_is_uniform */
 int eve_gate_top2_fwd(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C,
                       float* gates, int32_t* idx, int32_t* loc, int32_t* slot, float* weight,
                       int32_t* slot_token, float* slot_weight,

@@ -93,3 +93,36 @@ def assert_fp32_close(got, ref, name="", rtol=1e-5, floor=1e-5):
         raise AssertionError(f"{name}: fp32 bar (rtol {rtol} + {floor} x max|ref| = {floor * scale:.3g}) exceeded "
                              f"{used:.2f}-fold; worst: got {float(got.flatten()[i]):.8g} ref {float(ref.flatten()[i]):.8g}")
     return used
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) in numpy: the
+# published algorithm the gate's device noise source (include/eve_moe.h, EVE_NOISE_DEVICE_PHILOX) is specified by.
+# Pinned by the Random123 known-answer vectors in tests/test_host_cpu.py.
+def philox4x32_10(counter, key):
+    """counter [..., 4] uint32, key [..., 2] uint32 -> [..., 4] uint32."""
+    import numpy as np
+    c = [np.asarray(counter[..., i], dtype=np.uint64) for i in range(4)]
+    k = [np.asarray(key[..., i], dtype=np.uint64) for i in range(2)]
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k[0]) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k[1]) & m32, p0 & m32]
+        k = [(k[0] + np.uint64(0x9E3779B9)) & m32, (k[1] + np.uint64(0xBB67AE85)) & m32]
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def device_noise_uniforms(seed: int, offset: int, S: int, E: int):
+    """The [S,E] standard-uniform draws the gate makes from generator state {seed, offset} (header: element i is word
+    i & 3 of the block at counter offset + (i >> 2), mapped to [0,1) as (word >> 8) * 2^-24), fp32."""
+    import numpy as np
+    n4 = (S * E + 3) // 4
+    ctr = (np.arange(n4, dtype=np.uint64) + np.uint64(offset % (1 << 64)))
+    counter = np.zeros((n4, 4), np.uint32)
+    counter[:, 0] = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    counter[:, 1] = (ctr >> np.uint64(32)).astype(np.uint32)
+    seed %= 1 << 64
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32), (n4, 2))
+    words = philox4x32_10(counter, key).reshape(-1)[:S * E]
+    return ((words >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(S, E)

@@ -182,3 +182,24 @@ def test_fused_layer_buffer_layouts():
     assert inf >= fwd + E * C * (2 * M + I) * 2  # the activation buffers move into the workspace
     assert bwd >= E * C * (2 * M + I) * 2 + S * E * 4 + lib.eve_ffn_bwd_workspace_bytes(E, E, C, M, I, _lib.BF16)
     assert lib.eve_moe_saved_offsets(ref, 1, None, n) == -1 and lib.eve_moe_saved_bytes(None, 1) == 0
+
+
+def test_philox_reference_known_answers():
+    """The numpy Philox4x32-10 of tests/helpers.py (the checker of the gate's device noise source) against the
+    known-answer vectors of the Random123 distribution (kat_vectors: philox4x32 10)."""
+    import numpy as np
+    from tests.helpers import device_noise_uniforms, philox4x32_10
+
+    def run(c, k):
+        return [int(x) for x in philox4x32_10(np.array([c], np.uint32), np.array([k], np.uint32))[0]]
+
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    u = device_noise_uniforms(seed=7, offset=5, S=999, E=32)
+    assert u.dtype == np.float32 and u.shape == (999, 32) and 0.0 <= u.min() and u.max() < 1.0
+    assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float(u.var()) - 1 / 12) < 0.005
+    # a later offset continues the same stream: element i at offset o == element i - 4 at offset o + 1
+    v = device_noise_uniforms(seed=7, offset=6, S=999, E=32)
+    assert np.array_equal(u.reshape(-1)[4:], v.reshape(-1)[:-4])
