@@ -56,7 +56,7 @@ SIGNATURES = {
     "eve_moe_saved_bytes": (c_size_t, [_P, _I]),
     "eve_moe_workspace_bytes": (c_size_t, [_P, _I]),
     "eve_moe_saved_offsets": (c_int, [_P, _I, _P, _I]),
-    "eve_moe_fwd": (c_int, [_P] * 6 + [_I] + [_P] * 7 + [_Z, _I, _P, _Z, _P]),
+    "eve_moe_fwd": (c_int, [_P] * 6 + [_I] + [_P] * 8 + [_Z, _I, _P, _Z, _P]),
     "eve_moe_bwd": (c_int, [_P] * 10 + [_Z] + [_P] * 9 + [_Z, _P]),
     "eve_moe_route_fwd": (c_int, [_P] * 6 + [_I] + [_P] * 3 + [_Z, _P, _Z, _P]),
     "eve_moe_finish_fwd": (c_int, [_P, _P, _P, _Z, _P, _P]),

@@ -127,6 +127,11 @@ __device__ __forceinline__ int token_modality(int s, int T, int n_vis, int mode)
 }
 
 // permute.hip: the closing stage of the fused backward (eve_moe_bwd), eve_route_bwd + eve_gate_wgrad in two launches
+// gate.hip: eve_gate_top2_fwd whose closing kernel also writes exp_counts to `exp_counts_mirror` (NULL = no mirror)
+int gate_top2_fwd_mirrored(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C, float* gates,
+                           int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
+                           float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace,
+                           size_t workspace_bytes, void* stream, int64_t* exp_counts_mirror);
 bool combine_gate_bwd_fusable(const void* dout, const void* y, const int32_t* slot, const void* dy, const int32_t* idx,
                               const int32_t* loc, int M, int E, int dtype);
 int combine_bwd_gate_bwd(const void* dout, const void* y, const int32_t* slot, const int32_t* slot_token, const float* slot_weight,

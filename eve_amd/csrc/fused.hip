@@ -150,8 +150,9 @@ extern "C" int eve_moe_saved_offsets(const eve_moe_shape* p, int need_backward, 
 
 extern "C" int eve_moe_fwd(const eve_moe_shape* p, const void* h, const void* vision_embed, const void* text_embed,
                            const float* wg, const float* noise, int noise_is_uniform, const void* w1, const void* b1,
-                           const void* w2, const void* b2, void* out, float* l_aux, void* saved, size_t saved_bytes,
-                           int need_backward, void* workspace, size_t workspace_bytes, void* stream) {
+                           const void* w2, const void* b2, void* out, float* l_aux, int64_t* exp_counts_host,
+                           void* saved, size_t saved_bytes, int need_backward, void* workspace, size_t workspace_bytes,
+                           void* stream) {
   if (int rc = check_shape("eve_moe_fwd", p)) return rc;
   EVE_REQUIRE(h && wg && noise && w1 && b1 && w2 && b2 && out && l_aux && saved && workspace, EVE_ERR_ARG, "eve_moe_fwd: null pointer");
   const bool nb = need_backward != 0;
@@ -177,8 +178,9 @@ extern "C" int eve_moe_fwd(const eve_moe_shape* p, const void* h, const void* vi
   void* y = nb ? s + sv.off[SV_Y] : w + ws.off[WS_Y];
   const int n = p->E * p->C;
   if (int rc = eve_gate_logits_fwd(h, vision_embed, text_embed, wg, logits, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype, stream)) return rc;
-  if (int rc = eve_gate_top2_fwd(logits, noise, noise_is_uniform, p->S, p->E, p->C, gates, idx, loc, slot, weight, slot_token, slot_weight,
-                                 exp_counts, rows, l_aux, w + ws.off[WS_GATE], eve_gate_workspace_bytes(p->S, p->E), stream)) return rc;
+  if (int rc = eve::gate_top2_fwd_mirrored(logits, noise, noise_is_uniform, p->S, p->E, p->C, gates, idx, loc, slot, weight, slot_token,
+                                           slot_weight, exp_counts, rows, l_aux, w + ws.off[WS_GATE],
+                                           eve_gate_workspace_bytes(p->S, p->E), stream, exp_counts_host)) return rc;
   if (int rc = eve_dispatch_fwd(h, vision_embed, text_embed, slot, slot_token, xd, p->S, p->T, p->n_vis, p->mode, p->M, n, p->dtype, stream)) return rc;
   if (int rc = eve_ffn_fwd(xd, w1, b1, w2, b2, z, a, y, rows, p->E, p->E, p->C, p->M, p->I, p->act, p->dtype, 0, stream)) return rc;
   return eve_combine_fwd(y, slot, weight, out, p->S, p->M, p->dtype, stream);

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restri
                                                         int64_t* __restrict__ exp_counts, int32_t* __restrict__ rows,
                                                         float* __restrict__ l_aux, int S, int E, int C, int nblk,
                                                         unsigned long long* __restrict__ rng_state,
-                                                        unsigned long long rng_inc) {
+                                                        unsigned long long rng_inc, int64_t* __restrict__ exp_counts_mirror) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   philox_advance(rng_state, rng_inc);
   int32_t* stot = reinterpret_cast<int32_t*>(smem);   // [2E]
@@ -464,6 +464,7 @@ __global__ __launch_bounds__(1024) void gate_scan_kernel(const int32_t* __restri
   for (int t = threadIdx.x; t < 2 * E; t += blockDim.x) tot[t] = stot[t];
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     exp_counts[e] = (int64_t)stot[e];
+    if (exp_counts_mirror) exp_counts_mirror[e] = (int64_t)stot[e];
     const int filled = stot[e] + stot[E + e];
     rows[e] = filled < C ? filled : C;
   }
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(512) void gate_assign32_kernel(
     const int32_t* __restrict__ hist, const float* __restrict__ gsum, int S, int E, int C, int32_t* __restrict__ loc,
     int32_t* __restrict__ slot, float* __restrict__ weight, int32_t* __restrict__ slot_token,
     float* __restrict__ slot_weight, int64_t* __restrict__ exp_counts, int32_t* __restrict__ rows,
-    float* __restrict__ l_aux, unsigned long long* __restrict__ rng_state, unsigned long long rng_inc) {
+    float* __restrict__ l_aux, unsigned long long* __restrict__ rng_state, unsigned long long rng_inc,
+    int64_t* __restrict__ exp_counts_mirror) {
   __shared__ int32_t pbefore[8][64], pall[8][64];
   philox_advance(rng_state, rng_inc);
   __shared__ int32_t pre[64], tot[64];
@@ -584,6 +586,7 @@ __global__ __launch_bounds__(512) void gate_assign32_kernel(
       for (int q = 1; q < 16; ++q) gs += gpart[q][e];
       term[e] = (gs / (float)S) * ((float)tot[e] / (float)S);
       exp_counts[e] = (int64_t)tot[e];
+      if (exp_counts_mirror) exp_counts_mirror[e] = (int64_t)tot[e];
       const int filled = tot[e] + tot[E + e];
       rows[e] = filled < C ? filled : C;
     }
@@ -1237,7 +1240,7 @@ extern "C" size_t eve_gate_workspace_bytes(int S, int E) {
 static int gate_top2_launch(const float* logits, const float* noise, int noise_is_uniform, int S, int E,
                             int C, float* gates, int32_t* idx, int32_t* loc, int32_t* slot, float* weight,
                             int32_t* slot_token, float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux,
-                            char* ws, const GateWs& w, hipStream_t st) {
+                            char* ws, const GateWs& w, hipStream_t st, int64_t* exp_counts_mirror = nullptr) {
   int32_t* hist = reinterpret_cast<int32_t*>(ws + w.hist);
   int32_t* boff = reinterpret_cast<int32_t*>(ws + w.boff);
   int32_t* rank = reinterpret_cast<int32_t*>(ws + w.rank);
@@ -1265,13 +1268,13 @@ static int gate_top2_launch(const float* logits, const float* noise, int noise_i
   }
   if (fused_assign) {
     hipLaunchKernelGGL(gate_assign32_kernel, dim3(w.nblk), dim3(512), 0, st, gates, idx, rank, hist, gsum, S, E, C, loc,
-                       slot, weight, slot_token, slot_weight, exp_counts, rows, l_aux, rng_state, rng_inc);
+                       slot, weight, slot_token, slot_weight, exp_counts, rows, l_aux, rng_state, rng_inc, exp_counts_mirror);
     EVE_CHECK_LAUNCH("gate_assign32_kernel");
     return EVE_OK;
   }
   const size_t lds2 = (size_t)4 * E * 4;
   hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(1024), lds2, st, hist, boff, gsum, tot, exp_counts, rows, l_aux, S,
-                     E, C, w.nblk, rng_state, rng_inc);
+                     E, C, w.nblk, rng_state, rng_inc, exp_counts_mirror);
   EVE_CHECK_LAUNCH("gate_scan_kernel");
   hipLaunchKernelGGL(gate_assign_kernel, dim3(w.nblk), dim3(kGateBlock), 0, st, gates, idx, rank, boff, tot, S, E, C,
                      loc, slot, weight, slot_token, slot_weight);
@@ -1291,18 +1294,36 @@ static int gate_top2_launch(const float* logits, const float* noise, int noise_i
   EVE_REQUIRE(E <= 1024, EVE_ERR_UNSUPPORTED, who ": E=%d > 1024", E);                                                 \
   EVE_REQUIRE((long long)E * C < (1ll << 31), EVE_ERR_ARG, who ": E*C overflows int32")
 
+namespace eve {
+int gate_top2_fwd_mirrored(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C, float* gates,
+                           int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
+                           float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace,
+                           size_t workspace_bytes, void* stream, int64_t* exp_counts_mirror);
+}
 extern "C" int eve_gate_top2_fwd(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C, float* gates,
                                  int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
                                  float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux,
                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return eve::gate_top2_fwd_mirrored(logits, noise, noise_is_uniform, S, E, C, gates, idx, loc, slot, weight, slot_token,
+                                     slot_weight, exp_counts, rows, l_aux, workspace, workspace_bytes, stream, nullptr);
+}
+
+// eve_gate_top2_fwd with a second copy of exp_counts written by the same kernel (fused.hip: eve_moe_fwd's
+// exp_counts_host); arguments already checked by the caller's shape check except what is checked here
+namespace eve {
+int gate_top2_fwd_mirrored(const float* logits, const float* noise, int noise_is_uniform, int S, int E, int C, float* gates,
+                           int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
+                           float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace,
+                           size_t workspace_bytes, void* stream, int64_t* exp_counts_mirror) {
   EVE_GATE_TOP2_CHECK_ARGS("eve_gate_top2_fwd");
   EVE_REQUIRE(workspace, EVE_ERR_ARG, "eve_gate_top2_fwd: null workspace");
   const GateWs w = gate_ws_layout(S, E);
   EVE_REQUIRE(workspace_bytes >= w.total, EVE_ERR_WORKSPACE, "eve_gate_top2_fwd: workspace %zu < %zu", workspace_bytes, w.total);
   EVE_REQUIRE(((uintptr_t)workspace & 255) == 0, EVE_ERR_ARG, "eve_gate_top2_fwd: workspace must be 256-byte aligned");
-  return gate_top2_launch(logits, noise, noise_is_uniform, S, E, C, gates, idx, loc, slot, weight,
-                          slot_token, slot_weight, exp_counts, rows, l_aux, static_cast<char*>(workspace), w, S_(stream));
+  return gate_top2_launch(logits, noise, noise_is_uniform, S, E, C, gates, idx, loc, slot, weight, slot_token, slot_weight,
+                          exp_counts, rows, l_aux, static_cast<char*>(workspace), w, S_(stream), exp_counts_mirror);
 }
+}  // namespace eve
 
 // ---- the same gate for callers that cannot allocate (include/eve_moe.h: eve_gate_top2_fwd_noalloc) ------------
 // The scratch of the gate kernels lives in the code object instead of in caller memory.  Every GPU the library

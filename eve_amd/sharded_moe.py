@@ -472,7 +472,7 @@ class _FusedMoEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, wg, vemb, temb, noise, w1, b1, w2, b2, n_vis, mode, cap_factor, min_capacity,  # type: ignore[override]
-                noise_is_uniform, act, grad_mode):
+                noise_is_uniform, act, grad_mode, counts_host=None):
         B, T, M = h.shape
         S = B * T
         h2d = h.contiguous().view(S, M)
@@ -506,7 +506,8 @@ class _FusedMoEFn(torch.autograd.Function):
         l_aux = torch.empty((), dtype=torch.float32, device=dev)
         ops.PROFILE.call("eve_moe_fwd", ref, ops._p(h2d), ops._p(ve), ops._p(te), ops._p(wg32), ops._p(noise),
                          ncode, ops._p(w1), ops._p(b1), ops._p(w2), ops._p(b2), ops._p(out),
-                         ops._p(l_aux), ops._p(blob), nbytes, 1 if need_bwd else 0, ops._p(ws), nws, ops._stream())
+                         ops._p(l_aux), ops._p(counts_host), ops._p(blob), nbytes, 1 if need_bwd else 0, ops._p(ws), nws,
+                         ops._stream())
         o = offs["slot"]
         slot = blob[o:o + S * 8].view(torch.int32).view(S, 2)
         o = offs["exp_counts"]
@@ -553,7 +554,7 @@ class _FusedMoEFn(torch.autograd.Function):
             dv = dv.to(v_dt)
         if dte is not None and dte.dtype != t_dt:
             dte = dte.to(t_dt)
-        return (dh, dwg, dv, dte, None, dw1, db1, dw2, db2) + (None,) * 7
+        return (dh, dwg, dv, dte, None, dw1, db1, dw2, db2) + (None,) * 8
 
 
 
@@ -828,6 +829,17 @@ class MOELayer(nn.Module):
         else:
             raise ValueError("eve_amd.MOELayer.set_noise_source: 'torch' or 'device'")
 
+    def _pinned_counts(self, E: int) -> Tensor:
+        """The pinned host tensor a non-blocking forward returns exp_counts in: this layer's own persistent one under
+        HIP-graph capture (refilled by every replay), a fresh one per eager call (as `_host_counts` hands out)."""
+        if torch.cuda.is_current_stream_capturing():
+            if self._graph_counts_host is None or self._graph_counts_host.numel() != E:
+                raise RuntimeError("eve_amd: run the layer once eagerly before capturing it into a graph")
+            return self._graph_counts_host
+        if self._graph_counts_host is None or self._graph_counts_host.numel() != E:
+            self._graph_counts_host = torch.empty(E, dtype=torch.int64, pin_memory=True)
+        return torch.empty(E, dtype=torch.int64, pin_memory=True)
+
     def _host_counts(self, exp_counts: Tensor) -> Tensor:
         if torch.cuda.is_current_stream_capturing():
             # under HIP-graph capture nothing may be allocated or synchronised: the copy node targets this layer's
@@ -978,11 +990,13 @@ class MOELayer(nn.Module):
                 and E <= 32):
             # every expert is local: the whole layer is one C call per direction (eve_moe_fwd / eve_moe_bwd)
             w1, b1, w2, b2 = self.experts.packed_parameters(h.dtype)
+            # (non-blocking exp_counts: the gate's closing kernel writes them into the pinned host buffer itself)
+            counts_host = None if self.blocking_exp_counts else self._pinned_counts(E)
             out, l_aux, slot, exp_counts = _FusedMoEFn.apply(
                 h, gate.wg.weight, vemb_in, temb_in, noise, w1, b1, w2, b2, n_vis, code, gate.active_capacity_factor(),
-                gate.min_capacity, is_uniform, self.experts._act_code, torch.is_grad_enabled())
+                gate.min_capacity, is_uniform, self.experts._act_code, torch.is_grad_enabled(), counts_host)
             self.l_aux = l_aux
-            self.exp_counts = self._host_counts(exp_counts)
+            self.exp_counts = counts_host if counts_host is not None else self._host_counts(exp_counts)
             # a copy (S * 8 bytes): a view would keep the whole `saved` blob (xd, z, a, y: ~0.5 GB at the cfg-2 shape)
             # alive on the module after backward, until this layer's next forward
             self.last_slot = slot.clone() if self.track_last_slot else None

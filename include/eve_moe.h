@@ -298,11 +298,16 @@ int eve_moe_saved_offsets(const eve_moe_shape* shape, int need_backward, size_t*
  * eve_dispatch_fwd -> eve_ffn_fwd -> eve_combine_fwd.  h [S,M]; vision_embed / text_embed [M] (`dtype`; may be
  * NULL for EVE_MODE_NONE); wg [E,M] fp32; noise [S,E] as in eve_gate_top2_fwd; w1/b1/w2/b2 as in eve_ffn_fwd
  * with E_local = E.  need_backward == 0: inference (z is not stored, the activation buffers live in the
- * workspace, pass EVE_MOE_PASS_INFERENCE sizes it); != 0: EVE_MOE_PASS_FORWARD. */
+ * workspace, pass EVE_MOE_PASS_INFERENCE sizes it); != 0: EVE_MOE_PASS_FORWARD.
+ * exp_counts_host (since ABI 11, NULL = none): a second place where the gate's closing kernel writes exp_counts [E]
+ * int64 -- meant for pinned, device-visible HOST memory (hipHostMalloc), so that the `exp_counts.to('cpu')` the
+ * reference's layer returns (models/sharded_moe.py:199 via :381, layer.py:93) needs no copy of its own on the
+ * stream (inside a captured step: no copy node between the forward's and the backward's kernels); valid for the
+ * host once the stream has passed the call.  Any device-writable int64 [E] buffer will do. */
 int eve_moe_fwd(const eve_moe_shape* shape, const void* h, const void* vision_embed, const void* text_embed,
                 const float* wg, const float* noise, int noise_is_uniform, const void* w1, const void* b1,
-                const void* w2, const void* b2, void* out, float* l_aux, void* saved, size_t saved_bytes,
-                int need_backward, void* workspace, size_t workspace_bytes, void* stream);
+                const void* w2, const void* b2, void* out, float* l_aux, int64_t* exp_counts_host, void* saved,
+                size_t saved_bytes, int need_backward, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of eve_moe_fwd: eve_combine_bwd -> eve_ffn_bwd -> eve_gate_top2_bwd -> eve_route_bwd ->
  * eve_gate_wgrad.  In: dout [S,M], d_l_aux [1] device scalar (NULL = the auxiliary loss was not used), the

@@ -109,7 +109,7 @@ def test_fused_entry_points_reject_small_buffers_and_bad_shapes():
 
     def fwd(nsv, nw, shp=ref):
         return lib.eve_moe_fwd(shp, p(h), p(ve), p(te), p(wg), p(noise), 0, p(w1), p(b1), p(w2), p(b2), p(out), p(l_aux),
-                               p(saved), nsv, 1, p(ws), nw, None)
+                               None, p(saved), nsv, 1, p(ws), nw, None)
 
     assert fwd(nsaved, nws) == 0
     torch.cuda.synchronize()
@@ -153,3 +153,27 @@ def test_parameter_casts_follow_in_place_updates():
             moe.moe.text_embed.data.mul_(0.7)
             moe.moe.gate.wg.weight.data.add_(0.01)
             assert moe.moe.vision_embed._version == ver
+
+
+def test_exp_counts_written_to_pinned_host_memory_by_the_gate():
+    """eve_moe_fwd's exp_counts_host (ABI 11): with non-blocking exp_counts the layer hands back the pinned tensor the
+    gate's closing kernel filled -- no copy on the stream -- equal to the blocking layer's counts."""
+    from oracle import moe_oracle as orc
+    from tests.helpers import build_moe
+    M, I, E, B, n_vis, T = 64, 128, 32, 8, 9, 15
+    p = orc.make_params(M, I, E, seed=71)
+    h = orc.synth_hidden(B, T, M, seed=72).to(DEV)
+    noise = orc.gumbel_noise((B * T, E), generator=torch.Generator().manual_seed(73))
+    a, b = build_moe(p, M, I, E, n_vis, device=DEV), build_moe(p, M, I, E, n_vis, device=DEV)
+    b.moe.blocking_exp_counts = False
+    a.moe.noise_override, b.moe.noise_override = noise.to(DEV), noise.to(DEV)
+    _, _, ca = a(h, mode="vl")
+    _, _, cb = b(h, mode="vl")
+    assert cb.is_pinned() and cb.device.type == "cpu" and cb.dtype == torch.int64
+    torch.cuda.synchronize()
+    assert torch.equal(ca, cb) and int(cb.sum()) == B * T
+    # a second call must not overwrite the tensor handed out by the first (eager: a fresh pinned tensor per call)
+    b.moe.noise_override = orc.gumbel_noise((B * T, E), generator=torch.Generator().manual_seed(74)).to(DEV)
+    _, _, cb2 = b(h, mode="vl")
+    torch.cuda.synchronize()
+    assert cb2.data_ptr() != cb.data_ptr() and torch.equal(ca, cb)
