@@ -203,3 +203,28 @@ def test_philox_reference_known_answers():
     # a later offset continues the same stream: element i at offset o == element i - 4 at offset o + 1
     v = device_noise_uniforms(seed=7, offset=6, S=999, E=32)
     assert np.array_equal(u.reshape(-1)[4:], v.reshape(-1)[:-4])
+
+
+def test_noise_source_selection_and_device_noise_state():
+    """Host side of the gate's device noise source: state layout {seed, offset} as int64, distinct default seeds per
+    instance, snapshot / restore, and `set_noise_source` argument checking (no GPU involved)."""
+    import torch
+    import eve_amd
+    from eve_amd import DeviceNoise
+    a, b = DeviceNoise("cpu"), DeviceNoise("cpu")
+    assert a.state.dtype == torch.int64 and a.state.shape == (2,) and int(a.state[1]) == 0
+    assert int(a.state[0]) != int(b.state[0])
+    c = DeviceNoise("cpu", seed=(1 << 64) - 1)            # seeds are 64-bit unsigned, stored two's complement
+    assert int(c.state[0]) == -1
+    snap = c.snapshot()
+    c.state[1] = 77
+    c.restore(snap)
+    assert int(c.state[1]) == 0
+    moe = eve_amd.MoE(16, eve_amd.MultiwayTransformerMLP("quick_gelu", 16, 32), num_experts=4, k=2, num_tokens=3)
+    assert moe.moe.device_noise is None
+    moe.set_noise_source("device", seed=5)
+    assert int(moe.moe.device_noise.state[0]) == 5
+    moe.set_noise_source("torch")
+    assert moe.moe.device_noise is None
+    with pytest.raises(ValueError):
+        moe.set_noise_source("numpy")
