@@ -290,6 +290,34 @@ def time_layer(moe, h, dout, steps, warmup, train=True):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def torch_noise_companion(args, M, I, E, n_vis, dtype, dev, h, dout):
+    """The headline step once more with the Gumbel noise drawn by torch.rand from torch's device generator (the
+    reference's own source, sharded_moe.py:70-77), same layer parameters, same inputs, same timing protocol: what
+    the in-kernel draw of `value` is worth (the work per step is the same: one fresh [S,E] draw)."""
+    global DEVICE_NOISE
+    import eve_amd
+    DEVICE_NOISE = False
+    try:
+        moe = build_layer(M, I, E, 1, 0, n_vis, dtype, dev)
+    finally:
+        DEVICE_NOISE = True
+    moe.moe.track_last_slot = False
+    graphed = eve_amd.GraphedTrainStep(moe, h, dout, mode="vl")
+    for _ in range(args.warmup):
+        graphed()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graphed()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    S = h.shape[0] * h.shape[1]
+    del graphed, moe
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(ms, 4), "tokens_per_s": round(S / ms * 1e3, 1),
+            "gumbel_noise": "torch.rand on torch's device generator, inside the replayed graph"}
+
+
 def other_configs(dev, steps=10, warmup=4):
     """The other BASELINE.json layer shapes on ONE MI355X, all 32 experts local, eager issue, a few steps each
     (the headline entry above is configs[1]'s layer; configs[0] is the CPU case = cpu_baseline)."""
@@ -574,6 +602,8 @@ def main():
         if rehearsal:
             line["rehearsal"] = "all ranks on cuda:0 over gloo with a host-staged exchange: NOT a measurement"
         if world == 1:
+            if use_graph and DEVICE_NOISE:
+                line["same_step_with_torch_generator_noise"] = torch_noise_companion(args, M, I, E, n_vis, dtype, dev, h, dout)
             del moe, params, h, dout
             if use_graph:
                 del graphed, step

@@ -118,6 +118,10 @@ def _draw_noise(shape, device: torch.device, source: Optional[DeviceNoise] = Non
     -- also when a caller has replaced this module's `gumbel_rsample`, as the goldens' scripts do.  With a
     `DeviceNoise` source: its state, for the kernel to draw from (nothing is drawn here)."""
     if source is not None:
+        if source.state.device != torch.device(device):  # the module was moved after set_noise_source
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("eve_amd: the DeviceNoise state lives on another device than the layer's input")
+            source.state = source.state.to(device)
         return source.state, ops.NOISE_DEVICE_PHILOX
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
