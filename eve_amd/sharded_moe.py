@@ -94,7 +94,7 @@ class DeviceNoise:
     generator bookkeeping torch runs before every replay of a graph that holds a `torch.rand` (two fill kernels and
     a launch gap, ~25 us per step at the cfg-2 shape).  Stands for the draw of reference sharded_moe.py:186 where
     torch's generator STREAM is not needed; the values are not torch's, so `torch.manual_seed` does not steer them
-    and torch's RNG stashing (activation checkpointing) does not rewind them -- use `snapshot()` / `restore()`."""
+    (`snapshot()` / `restore()` do).  Activation-checkpoint recomputes replay the draw: see `for_this_forward`."""
 
     _instances = 0
 
@@ -104,12 +104,30 @@ class DeviceNoise:
         DeviceNoise._instances += 1
         seed = int(seed) % (1 << 64)
         self.state = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed, 0], dtype=torch.int64, device=device)
+        import collections
+        self._stash = collections.deque(maxlen=64)  # states that recent forwards started from (see for_this_forward)
 
     def snapshot(self) -> Tensor:
         return self.state.clone()
 
     def restore(self, snap: Tensor) -> None:
         self.state.copy_(snap)
+
+    def for_this_forward(self) -> Tensor:
+        """The state tensor the gate of the forward being issued should draw from (and advance).  A forward issued
+        from INSIDE a backward pass is an activation-checkpoint recompute (reference multiway_transformer.py:574-586,
+        fairscale's checkpoint_wrapper, VQA.py:239-244): it must see the noise of the forward it repeats, so every
+        ordinary forward leaves a 16-byte copy of the state it started from on a short stack and a recompute draws
+        from the most recent one (segments are recomputed in reverse order) without touching the live state.  Under
+        HIP-graph capture nothing is stashed (a captured step is never recomputed)."""
+        if torch._C._current_graph_task_id() != -1:  # inside autograd's backward: a recompute
+            if self._stash:
+                return self._stash.pop()
+            raise RuntimeError("eve_amd.DeviceNoise: a forward was re-executed inside backward (activation "
+                               "checkpointing) but no state of an earlier forward is on record")
+        if not torch.cuda.is_current_stream_capturing():
+            self._stash.append(self.state.clone())
+        return self.state
 
 
 def _draw_noise(shape, device: torch.device, source: Optional[DeviceNoise] = None) -> Tuple[Tensor, int]:
@@ -122,7 +140,8 @@ def _draw_noise(shape, device: torch.device, source: Optional[DeviceNoise] = Non
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("eve_amd: the DeviceNoise state lives on another device than the layer's input")
             source.state = source.state.to(device)
-        return source.state, ops.NOISE_DEVICE_PHILOX
+            source._stash.clear()
+        return source.for_this_forward(), ops.NOISE_DEVICE_PHILOX
     device = torch.device(device)
     if device.index is None and device.type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())

@@ -224,8 +224,9 @@ def test_rng_replay_matches():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("noise_source", ["torch", "device"])
 @pytest.mark.parametrize("use_reentrant", [False, True])
-def test_activation_checkpoint_recompute_replays_the_gumbel_draw(use_reentrant):
+def test_activation_checkpoint_recompute_replays_the_gumbel_draw(use_reentrant, noise_source):
     """The reference re-executes the layer under activation checkpointing (multiway_transformer.py:574-586,
     fairscale checkpoint_wrapper VQA.py:239): torch's checkpoint stashes and restores the device RNG state, and the
     layer draws its noise with one torch.rand from the global generator, so the recomputed forward must route
@@ -236,6 +237,11 @@ def test_activation_checkpoint_recompute_replays_the_gumbel_draw(use_reentrant):
     h0 = orc.synth_hidden(B, T, M, seed=1).to(DEV)
     dout = torch.randn(B, T, M, generator=torch.Generator().manual_seed(2)).to(DEV)
     slots = []
+    if noise_source == "device":
+        # the gate draws from its own device state: a forward issued inside backward (the recompute) draws from the
+        # state its first execution started from (eve_amd.DeviceNoise.for_this_forward), the live state moves once
+        moe.set_noise_source("device", seed=11)
+        start = moe.moe.device_noise.snapshot()
 
     def body(x):
         out, l_aux, _ = moe(x, mode="vl")
@@ -247,6 +253,8 @@ def test_activation_checkpoint_recompute_replays_the_gumbel_draw(use_reentrant):
             p.grad = None
         slots.clear()
         torch.manual_seed(77)
+        if noise_source == "device":
+            moe.moe.device_noise.restore(start)
         x = h0.clone().requires_grad_(True)
         # (the non-reentrant form stops its recompute as soon as the last saved tensor exists again, which is before
         # body() records the slots: early stop off, so that the whole forward is re-executed as the reference's does)
@@ -263,6 +271,8 @@ def test_activation_checkpoint_recompute_replays_the_gumbel_draw(use_reentrant):
     assert torch.equal(s_a[0], s_b[0])
     assert torch.equal(out_a, out_b) and torch.equal(dh_a, dh_b)
     assert all(torch.equal(a, b) for a, b in zip(g_a, g_b))
+    if noise_source == "device":  # one draw per step, recompute or not
+        assert int(moe.moe.device_noise.state[1]) == int(start[1]) + B * T * E // 4
 
 
 @pytest.mark.parametrize("mode", ["vl", "vision", "plain"])
