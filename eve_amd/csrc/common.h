@@ -132,6 +132,14 @@ int gate_top2_fwd_mirrored(const float* logits, const float* noise, int noise_is
                            int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token,
                            float* slot_weight, int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace,
                            size_t workspace_bytes, void* stream, int64_t* exp_counts_mirror);
+// gate.hip: eve_gate_logits_fwd + eve_gate_top2_fwd as two launches (logits with the selection in their tail, then the
+// assignment), for the shapes gate_logits_top2_fusable accepts; same results as the two calls
+bool gate_logits_top2_fusable(int S, int M, int E, int dtype);
+int gate_logits_top2_fused(const void* h, const void* ve, const void* te, const float* wg, const float* noise,
+                           int noise_is_uniform, int S, int T_, int n_vis, int mode, int M, int E, int C, float* gates,
+                           int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token, float* slot_weight,
+                           int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace, size_t workspace_bytes,
+                           void* stream, int64_t* exp_counts_mirror);
 bool combine_gate_bwd_fusable(const void* dout, const void* y, const int32_t* slot, const void* dy, const int32_t* idx,
                               const int32_t* loc, int M, int E, int dtype);
 int combine_bwd_gate_bwd(const void* dout, const void* y, const int32_t* slot, const int32_t* slot_token, const float* slot_weight,

@@ -177,10 +177,17 @@ extern "C" int eve_moe_fwd(const eve_moe_shape* p, const void* h, const void* vi
   void* a = nb ? s + sv.off[SV_A] : w + ws.off[WS_A];
   void* y = nb ? s + sv.off[SV_Y] : w + ws.off[WS_Y];
   const int n = p->E * p->C;
-  if (int rc = eve_gate_logits_fwd(h, vision_embed, text_embed, wg, logits, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype, stream)) return rc;
-  if (int rc = eve::gate_top2_fwd_mirrored(logits, noise, noise_is_uniform, p->S, p->E, p->C, gates, idx, loc, slot, weight, slot_token,
-                                           slot_weight, exp_counts, rows, l_aux, w + ws.off[WS_GATE],
-                                           eve_gate_workspace_bytes(p->S, p->E), stream, exp_counts_host)) return rc;
+  if (eve::gate_logits_top2_fusable(p->S, p->M, p->E, p->dtype)) {  // logits + selection in one launch, then the assignment
+    if (int rc = eve::gate_logits_top2_fused(h, vision_embed, text_embed, wg, noise, noise_is_uniform, p->S, p->T, p->n_vis,
+                                             p->mode, p->M, p->E, p->C, gates, idx, loc, slot, weight, slot_token, slot_weight,
+                                             exp_counts, rows, l_aux, w + ws.off[WS_GATE],
+                                             eve_gate_workspace_bytes(p->S, p->E), stream, exp_counts_host)) return rc;
+  } else {
+    if (int rc = eve_gate_logits_fwd(h, vision_embed, text_embed, wg, logits, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype, stream)) return rc;
+    if (int rc = eve::gate_top2_fwd_mirrored(logits, noise, noise_is_uniform, p->S, p->E, p->C, gates, idx, loc, slot, weight, slot_token,
+                                             slot_weight, exp_counts, rows, l_aux, w + ws.off[WS_GATE],
+                                             eve_gate_workspace_bytes(p->S, p->E), stream, exp_counts_host)) return rc;
+  }
   if (int rc = eve_dispatch_fwd(h, vision_embed, text_embed, slot, slot_token, xd, p->S, p->T, p->n_vis, p->mode, p->M, n, p->dtype, stream)) return rc;
   if (int rc = eve_ffn_fwd(xd, w1, b1, w2, b2, z, a, y, rows, p->E, p->E, p->C, p->M, p->I, p->act, p->dtype, 0, stream)) return rc;
   return eve_combine_fwd(y, slot, weight, out, p->S, p->M, p->dtype, stream);
@@ -269,13 +276,24 @@ extern "C" int eve_moe_route_fwd(const eve_moe_shape* p, const void* h, const vo
   float* logits = reinterpret_cast<float*>(w + ws.off[WS_LOGITS]);
   int32_t* slot = reinterpret_cast<int32_t*>(s + sv.off[SV_SLOT]);
   int32_t* slot_token = reinterpret_cast<int32_t*>(s + sv.off[SV_SLOT_TOKEN]);
-  if (int rc = eve_gate_logits_fwd(h, vision_embed, text_embed, wg, logits, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype, stream)) return rc;
-  if (int rc = eve_gate_top2_fwd(logits, noise, noise_is_uniform, p->S, p->E, p->C, reinterpret_cast<float*>(s + sv.off[SV_GATES]),
-                                 reinterpret_cast<int32_t*>(s + sv.off[SV_IDX]), reinterpret_cast<int32_t*>(s + sv.off[SV_LOC]), slot,
-                                 reinterpret_cast<float*>(s + sv.off[SV_WEIGHT]), slot_token,
-                                 reinterpret_cast<float*>(s + sv.off[SV_SLOT_WEIGHT]), reinterpret_cast<int64_t*>(s + sv.off[SV_EXP_COUNTS]),
-                                 reinterpret_cast<int32_t*>(s + sv.off[SV_ROWS]), l_aux, w + ws.off[WS_GATE],
-                                 eve_gate_workspace_bytes(p->S, p->E), stream)) return rc;
+  float* gates = reinterpret_cast<float*>(s + sv.off[SV_GATES]);
+  int32_t* idx = reinterpret_cast<int32_t*>(s + sv.off[SV_IDX]);
+  int32_t* loc = reinterpret_cast<int32_t*>(s + sv.off[SV_LOC]);
+  float* weight = reinterpret_cast<float*>(s + sv.off[SV_WEIGHT]);
+  float* slot_weight = reinterpret_cast<float*>(s + sv.off[SV_SLOT_WEIGHT]);
+  int64_t* exp_counts = reinterpret_cast<int64_t*>(s + sv.off[SV_EXP_COUNTS]);
+  int32_t* rows = reinterpret_cast<int32_t*>(s + sv.off[SV_ROWS]);
+  if (eve::gate_logits_top2_fusable(p->S, p->M, p->E, p->dtype)) {  // as in eve_moe_fwd
+    if (int rc = eve::gate_logits_top2_fused(h, vision_embed, text_embed, wg, noise, noise_is_uniform, p->S, p->T, p->n_vis,
+                                             p->mode, p->M, p->E, p->C, gates, idx, loc, slot, weight, slot_token, slot_weight,
+                                             exp_counts, rows, l_aux, w + ws.off[WS_GATE],
+                                             eve_gate_workspace_bytes(p->S, p->E), stream, nullptr)) return rc;
+  } else {
+    if (int rc = eve_gate_logits_fwd(h, vision_embed, text_embed, wg, logits, p->S, p->T, p->n_vis, p->mode, p->M, p->E, p->dtype, stream)) return rc;
+    if (int rc = eve_gate_top2_fwd(logits, noise, noise_is_uniform, p->S, p->E, p->C, gates, idx, loc, slot, weight, slot_token,
+                                   slot_weight, exp_counts, rows, l_aux, w + ws.off[WS_GATE],
+                                   eve_gate_workspace_bytes(p->S, p->E), stream)) return rc;
+  }
   return eve_dispatch_fwd(h, vision_embed, text_embed, slot, slot_token, xd, p->S, p->T, p->n_vis, p->mode, p->M, p->E * p->C, p->dtype, stream);
 }
 

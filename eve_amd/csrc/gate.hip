@@ -235,22 +235,22 @@ __device__ __forceinline__ void argmax_quad(float& v, int& i) {
 // Gumbel variates, or (noise_is_uniform) the standard-uniform draws they are made of, transformed here.
 // Part B is the ballot ranking of the kernel above with the experts split over the four waves.  Same
 // outputs and workspace layout; also clears slot_token / slot_weight for pass 3.
-template <bool E32>
-__global__ __launch_bounds__(256) void gate_select32_kernel(
-    const float* __restrict__ logits, const float* __restrict__ noise, int noise_is_uniform, int S, int E,
+// The body of gate_select32_kernel for the block's first 256 threads (waves 0-3; a larger block's other waves only
+// take part in the clearing loop and the barriers).  LDS_LOGITS: the block's logits come from `lds_logits` [64][33]
+// (gate_logits_select_kernel) instead of global memory -- same values, same arithmetic.
+template <bool E32, bool LDS_LOGITS>
+__device__ __forceinline__ void gate_select32_body(
+    const float* __restrict__ logits, const float* lds_logits, const float* __restrict__ noise, int noise_is_uniform, int S, int E,
     float* __restrict__ gates, int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank,
     float* __restrict__ gsum, int32_t* __restrict__ slot_token, float* __restrict__ slot_weight, int num_slots,
-    int block_major) {
-  __shared__ int ci1[kGateBlock], ci2[kGateBlock];
-  __shared__ float tile[kGateBlock][33];
-  __shared__ float gpart[8][32];
+    int block_major, int* ci1, int* ci2, float (*tile)[33], float (*gpart)[32]) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < num_slots; i += gridDim.x * blockDim.x) {
     slot_token[i] = -1;
     slot_weight[i] = 0.f;
   }
 
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  {
+  if (wave < 4) {
     const int q = lane & 3, t = wave * 16 + (lane >> 2);  // token inside the block
     const int s = blockIdx.x * kGateBlock + t;
     const bool live = s < S;
@@ -259,9 +259,14 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
     const bool own_draws = noise_is_uniform == kNoisePhilox;
     const unsigned long long* rng = reinterpret_cast<const unsigned long long*>(noise);
     if (E32) {
-      const float4* lp = reinterpret_cast<const float4*>(logits + (size_t)(live ? s : 0) * 32 + e0);
-      const float4 a = lp[0], b = lp[1];
-      x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
+      if constexpr (LDS_LOGITS) {  // (the block's own logits, left in LDS by the kernel that formed them)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = lds_logits[t * 33 + e0 + j];
+      } else {
+        const float4* lp = reinterpret_cast<const float4*>(logits + (size_t)(live ? s : 0) * 32 + e0);
+        const float4 a = lp[0], b = lp[1];
+        x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
+      }
       if (own_draws) {  // the lane's eight elements are two whole Philox blocks
         const unsigned long long c0 = rng[1] + ((unsigned long long)(live ? s : 0) * 32 + e0) / 4;
         const Philox4 p = philox4x32_10(c0, rng[0]), r = philox4x32_10(c0 + 1, rng[0]);
@@ -276,7 +281,8 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const size_t o = (size_t)(live ? s : 0) * E + min(e0 + j, E - 1);
-        x[j] = logits[o];
+        if constexpr (LDS_LOGITS) x[j] = lds_logits[t * 33 + min(e0 + j, E - 1)];
+        else x[j] = logits[o];
         nz[j] = own_draws ? philox_uniform_at(rng, o) : noise[o];
       }
     }
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
     }
   }
   __syncthreads();
-  {  // per-block column sums of the gates (for l_aux), fixed order: 8 rows per thread, then 8 partials
+  if (threadIdx.x < 256) {  // per-block column sums of the gates (for l_aux), fixed order: 8 rows per thread, then 8 partials
     const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
     float p = 0.f;
 #pragma unroll
@@ -354,6 +360,7 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
   }
 
   // part B: lane = token
+  if (wave >= 4) return;
   const int s = blockIdx.x * kGateBlock + lane;
   const int i1 = ci1[lane], i2 = ci2[lane];
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -371,6 +378,19 @@ __global__ __launch_bounds__(256) void gate_select32_kernel(
     idx[2 * s] = i1;
     idx[2 * s + 1] = i2;
   }
+}
+
+template <bool E32>
+__global__ __launch_bounds__(256) void gate_select32_kernel(
+    const float* __restrict__ logits, const float* __restrict__ noise, int noise_is_uniform, int S, int E,
+    float* __restrict__ gates, int32_t* __restrict__ idx, int32_t* __restrict__ hist, int32_t* __restrict__ rank,
+    float* __restrict__ gsum, int32_t* __restrict__ slot_token, float* __restrict__ slot_weight, int num_slots,
+    int block_major) {
+  __shared__ int ci1[kGateBlock], ci2[kGateBlock];
+  __shared__ float tile[kGateBlock][33];
+  __shared__ float gpart[8][32];
+  gate_select32_body<E32, false>(logits, nullptr, noise, noise_is_uniform, S, E, gates, idx, hist, rank, gsum, slot_token,
+                                 slot_weight, num_slots, block_major, ci1, ci2, tile, gpart);
 }
 
 // Pass 2 (scan): single block.  Exclusive prefix of the block histograms over blocks for each
@@ -876,13 +896,14 @@ __global__ __launch_bounds__(256) void gate_logits_mfma_kernel(const T* __restri
 // per workgroup, not once per 32 tokens: the split is ~10 VALU instructions per element and was redone by every one
 // of the S / 32 blocks -- in registers across the tiles; the rows of the next tile are in flight while the current
 // one is multiplied, reduced over the waves through LDS in wave order (deterministic) and stored.
-template <bool EMB, int KB>
-__global__ __launch_bounds__(512) void gate_logits_walk_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ vemb,
-                                                               const bf16_t* __restrict__ temb,
-                                                               const float* __restrict__ wg, float* __restrict__ logits,
-                                                               int S, int T_, int n_vis, int mode, int M, int E,
-                                                               int ntiles, int tiles_per_block) {
-  __shared__ float red[8][16][64];
+// (body shared by the two kernels below; TO_LDS: the logits of the workgroup's tiles are also left in `lds_logits`
+// [tiles * 32][33], `logits` may then be NULL)
+template <bool EMB, int KB, bool TO_LDS>
+__device__ __forceinline__ void gate_logits_walk_body(const bf16_t* __restrict__ h, const bf16_t* __restrict__ vemb,
+                                                      const bf16_t* __restrict__ temb, const float* __restrict__ wg,
+                                                      float* __restrict__ logits, int S, int T_, int n_vis, int mode, int M,
+                                                      int E, int ntiles, int tiles_per_block, float (*red)[16][64],
+                                                      float* lds_logits) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int i = lane & 31, hh = lane >> 5;
@@ -968,11 +989,45 @@ __global__ __launch_bounds__(512) void gate_logits_walk_kernel(const bf16_t* __r
 #pragma unroll
         for (int w = 1; w < 8; ++w) v += red[w][r][lane];
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (t * 32 + row < S) logits[(size_t)(t * 32 + row) * E + i] = v;
+        if (logits && t * 32 + row < S) logits[(size_t)(t * 32 + row) * E + i] = v;
+        if constexpr (TO_LDS) lds_logits[((t - t_begin) * 32 + row) * 33 + i] = v;
       }
     }
     __syncthreads();
   }
+}
+
+template <bool EMB, int KB>
+__global__ __launch_bounds__(512) void gate_logits_walk_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ vemb,
+                                                               const bf16_t* __restrict__ temb,
+                                                               const float* __restrict__ wg, float* __restrict__ logits,
+                                                               int S, int T_, int n_vis, int mode, int M, int E,
+                                                               int ntiles, int tiles_per_block) {
+  __shared__ float red[8][16][64];
+  gate_logits_walk_body<EMB, KB, false>(h, vemb, temb, wg, logits, S, T_, n_vis, mode, M, E, ntiles, tiles_per_block, red, nullptr);
+}
+
+// The walking logits kernel with the gate's selection pass in its tail (the fused layer calls; E <= 32 and at most
+// kAssign32MaxBlocks blocks of 64 tokens): workgroup b forms the logits of tokens [64 b, 64 b + 64) -- two tiles --,
+// leaves them in LDS and runs gate_select32_body on them: the logits never travel through memory and the selection
+// costs no launch of its own (7.5 us for 6 MB, all of it latency).  Same arithmetic per logit and per selection as
+// gate_logits_walk_kernel followed by gate_select32_kernel, hence the same results bit for bit.
+template <bool EMB, int KB, bool E32>
+__global__ __launch_bounds__(512) void gate_logits_select_kernel(
+    const bf16_t* __restrict__ h, const bf16_t* __restrict__ vemb, const bf16_t* __restrict__ temb,
+    const float* __restrict__ wg, float* __restrict__ logits, int S, int T_, int n_vis, int mode, int M, int E, int ntiles,
+    const float* __restrict__ noise, int noise_is_uniform, float* __restrict__ gates, int32_t* __restrict__ idx,
+    int32_t* __restrict__ hist, int32_t* __restrict__ rank, float* __restrict__ gsum, int32_t* __restrict__ slot_token,
+    float* __restrict__ slot_weight, int num_slots) {
+  __shared__ float red[8][16][64];
+  __shared__ float lds_logits[kGateBlock * 33];
+  __shared__ int ci1[kGateBlock], ci2[kGateBlock];
+  __shared__ float tile[kGateBlock][33];
+  __shared__ float gpart[8][32];
+  gate_logits_walk_body<EMB, KB, true>(h, vemb, temb, wg, logits, S, T_, n_vis, mode, M, E, ntiles, 2, red, lds_logits);
+  __syncthreads();
+  gate_select32_body<E32, true>(nullptr, lds_logits, noise, noise_is_uniform, S, E, gates, idx, hist, rank, gsum, slot_token,
+                                slot_weight, num_slots, 1, ci1, ci2, tile, gpart);
 }
 
 // dwg partials: D[32 experts x 32 "virtual" cols] += A[32 experts x 2 tokens] * B[2 tokens x 32 cols].
@@ -1322,6 +1377,64 @@ int gate_top2_fwd_mirrored(const float* logits, const float* noise, int noise_is
   EVE_REQUIRE(((uintptr_t)workspace & 255) == 0, EVE_ERR_ARG, "eve_gate_top2_fwd: workspace must be 256-byte aligned");
   return gate_top2_launch(logits, noise, noise_is_uniform, S, E, C, gates, idx, loc, slot, weight, slot_token, slot_weight,
                           exp_counts, rows, l_aux, static_cast<char*>(workspace), w, S_(stream), exp_counts_mirror);
+}
+}  // namespace eve
+
+// ---- eve_gate_logits_fwd + eve_gate_top2_fwd of the fused layer calls in TWO launches (fused.hip) ----------------
+// gate_logits_select_kernel (logits and selection) + gate_assign32_kernel.  Only for the shapes those kernels are
+// written for; the caller asks gate_logits_top2_fusable first and otherwise makes the two calls.
+namespace eve {
+bool gate_logits_top2_fusable(int S, int M, int E, int dtype) {
+  return dtype == EVE_BF16 && E == 32 && S > 0 && M > 0 && M % 16 == 0 && ceil_div(M / 16, 8) <= 8 &&
+         ceil_div(S, kGateBlock) <= kAssign32MaxBlocks;
+}
+
+int gate_logits_top2_fused(const void* h, const void* ve, const void* te, const float* wg, const float* noise,
+                           int noise_is_uniform, int S, int T_, int n_vis, int mode, int M, int E, int C, float* gates,
+                           int32_t* idx, int32_t* loc, int32_t* slot, float* weight, int32_t* slot_token, float* slot_weight,
+                           int64_t* exp_counts, int32_t* rows, float* l_aux, void* workspace, size_t workspace_bytes,
+                           void* stream, int64_t* exp_counts_mirror) {
+  const float* logits = wg;  // (the argument check below wants a non-null `logits`; none exists on this path)
+  EVE_GATE_TOP2_CHECK_ARGS("eve_moe_fwd (gate)");
+  EVE_REQUIRE(h && wg && workspace, EVE_ERR_ARG, "eve_moe_fwd (gate): null pointer");
+  EVE_REQUIRE(gate_logits_top2_fusable(S, M, E, EVE_BF16), EVE_ERR_UNSUPPORTED, "eve_moe_fwd (gate): shape not fusable");
+  EVE_REQUIRE(mode >= EVE_MODE_NONE && mode <= EVE_MODE_TEXT, EVE_ERR_ARG, "eve_moe_fwd (gate): bad mode %d", mode);
+  if (mode != EVE_MODE_NONE) {
+    EVE_REQUIRE(ve && te, EVE_ERR_ARG, "eve_moe_fwd (gate): modality embeddings required for mode %d", mode);
+    EVE_REQUIRE(T_ > 0 && S % T_ == 0 && n_vis >= 0, EVE_ERR_ARG, "eve_moe_fwd (gate): S=%d not a multiple of T=%d", S, T_);
+  }
+  const GateWs w = gate_ws_layout(S, E);
+  EVE_REQUIRE(workspace_bytes >= w.total, EVE_ERR_WORKSPACE, "eve_moe_fwd (gate): workspace %zu < %zu", workspace_bytes, w.total);
+  EVE_REQUIRE(((uintptr_t)workspace & 255) == 0, EVE_ERR_ARG, "eve_moe_fwd (gate): workspace must be 256-byte aligned");
+  char* ws = static_cast<char*>(workspace);
+  int32_t* hist = reinterpret_cast<int32_t*>(ws + w.hist);
+  int32_t* rank = reinterpret_cast<int32_t*>(ws + w.rank);
+  float* gsum = reinterpret_cast<float*>(ws + w.gsum);
+  hipStream_t st = S_(stream);
+  const int ntiles = ceil_div(S, 32), kb = ceil_div(M / 16, 8);
+#define EVE_WALKSEL(KB_)                                                                                               \
+  case KB_:                                                                                                            \
+    if (mode != EVE_MODE_NONE)                                                                                         \
+      hipLaunchKernelGGL((gate_logits_select_kernel<true, KB_, true>), dim3(w.nblk), dim3(512), 0, st, (const bf16_t*)h, \
+                         (const bf16_t*)ve, (const bf16_t*)te, wg, (float*)nullptr, S, T_, n_vis, mode, M, E, ntiles,  \
+                         noise, noise_is_uniform, gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C);       \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gate_logits_select_kernel<false, KB_, true>), dim3(w.nblk), dim3(512), 0, st, (const bf16_t*)h, \
+                         (const bf16_t*)ve, (const bf16_t*)te, wg, (float*)nullptr, S, T_, n_vis, mode, M, E, ntiles,  \
+                         noise, noise_is_uniform, gates, idx, hist, rank, gsum, slot_token, slot_weight, E * C);       \
+    break;
+  switch (kb) {
+    EVE_WALKSEL(1) EVE_WALKSEL(2) EVE_WALKSEL(3) EVE_WALKSEL(4) EVE_WALKSEL(5) EVE_WALKSEL(6) EVE_WALKSEL(7) EVE_WALKSEL(8)
+  }
+#undef EVE_WALKSEL
+  EVE_CHECK_LAUNCH("gate_logits_select_kernel");
+  unsigned long long* rng_state = noise_is_uniform == kNoisePhilox
+                                      ? reinterpret_cast<unsigned long long*>(const_cast<float*>(noise)) : nullptr;
+  const unsigned long long rng_inc = ((unsigned long long)S * E + 3) / 4;
+  hipLaunchKernelGGL(gate_assign32_kernel, dim3(w.nblk), dim3(512), 0, st, gates, idx, rank, hist, gsum, S, E, C, loc, slot,
+                     weight, slot_token, slot_weight, exp_counts, rows, l_aux, rng_state, rng_inc, exp_counts_mirror);
+  EVE_CHECK_LAUNCH("gate_assign32_kernel");
+  return EVE_OK;
 }
 }  // namespace eve
 

@@ -62,6 +62,7 @@ alg = {  # kernel -> (algorithmic bytes, flops, note)
     "gate_logits_mfma_kernel": (S * M * b + 4 * S * E, 2.0 * S * M * E, "S*M*b + 4*S*E"),
     "gate_logits_walk_kernel": (S * M * b + 4 * S * E, 2.0 * S * M * E, "S*M*b + 4*S*E"),
     "gate_select32_kernel": (12 * E * S, 0, "logits + draws in, gates out: 12E B/token"),
+    "gate_logits_select_kernel": (S * M * b + (4 * E + 24) * S, 2.0 * S * M * E, "rows in, gates + choices out (logits and noise never travel)"),
     "gate_assign32_kernel": (40 * S, 0, "idx/rank in, loc/slot/weight + slot maps out"),
     "dispatch_fwd_kernel": ((S + K) * M * b, 0, "(S+K)*M*b"),
     "dispatch_fwd_tok_kernel": ((S + K) * M * b, 0, "(S+K)*M*b"),
