@@ -830,6 +830,8 @@ class MOELayer(nn.Module):
         # `last_slot` ([S,2] token -> slot map of the latest forward, diagnostics) is a COPY on the fused paths (their
         # map lives in the saved-state blob); False skips that copy (one ~5 us copy node of a captured step)
         self.track_last_slot = True
+        import collections
+        self._counts_in_flight = collections.deque()  # (event, pinned exp_counts tensor) of calls the stream has not passed
         self.device_noise: Optional[DeviceNoise] = None  # set_noise_source("device"): the gate draws its own noise
 
         self.num_vision_tokens = None
@@ -861,7 +863,19 @@ class MOELayer(nn.Module):
             return self._graph_counts_host
         if self._graph_counts_host is None or self._graph_counts_host.numel() != E:
             self._graph_counts_host = torch.empty(E, dtype=torch.int64, pin_memory=True)
+        # The gate kernel writes through the raw pointer, which torch's pinned-memory allocator does not know about
+        # (a `copy_(non_blocking=True)` would have recorded the stream on the block): the layer keeps every buffer it
+        # hands out alive until the stream has passed the call that fills it, so that a caller who drops the tensor
+        # early cannot have its block recycled under a write that is still queued.
+        while self._counts_in_flight and self._counts_in_flight[0][0].query():
+            self._counts_in_flight.popleft()
         return torch.empty(E, dtype=torch.int64, pin_memory=True)
+
+    def _counts_issued(self, counts_host: Tensor) -> None:
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            self._counts_in_flight.append((ev, counts_host))
 
     def _host_counts(self, exp_counts: Tensor) -> Tensor:
         if torch.cuda.is_current_stream_capturing():
@@ -1019,6 +1033,8 @@ class MOELayer(nn.Module):
                 h, gate.wg.weight, vemb_in, temb_in, noise, w1, b1, w2, b2, n_vis, code, gate.active_capacity_factor(),
                 gate.min_capacity, is_uniform, self.experts._act_code, torch.is_grad_enabled(), counts_host)
             self.l_aux = l_aux
+            if counts_host is not None:
+                self._counts_issued(counts_host)
             self.exp_counts = counts_host if counts_host is not None else self._host_counts(exp_counts)
             # a copy (S * 8 bytes): a view would keep the whole `saved` blob (xd, z, a, y: ~0.5 GB at the cfg-2 shape)
             # alive on the module after backward, until this layer's next forward
