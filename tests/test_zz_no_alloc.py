@@ -22,7 +22,7 @@ def _noalloc(logits, noise, C, noise_is_uniform=False):
                     torch.full((E * C,), 7.0, **f32), torch.full((E,), -7, dtype=torch.int64, device=dev),
                     torch.full((E,), -7, **i32), torch.full((1,), 7.0, **f32))
     p = lambda t: t.data_ptr()
-    _lib.call("eve_gate_top2_fwd_noalloc", p(logits), p(noise), 1 if noise_is_uniform else 0, S, E, C, p(r.gates), p(r.idx),
+    _lib.call("eve_gate_top2_fwd_noalloc", p(logits), p(noise), int(noise_is_uniform), S, E, C, p(r.gates), p(r.idx),
               p(r.loc), p(r.slot), p(r.weight), p(r.slot_token), p(r.slot_weight), p(r.exp_counts), p(r.rows), p(r.l_aux),
               torch.cuda.current_stream().cuda_stream)
     return r
@@ -60,3 +60,20 @@ def test_noalloc_gate_rejects_inputs_beyond_its_buffer():
     torch.cuda.synchronize()
     for name in FIELDS:
         assert torch.equal(getattr(got, name), getattr(want, name)), name
+
+
+def test_noalloc_gate_draws_from_a_device_generator_state():
+    """noise_is_uniform == 2 (the gate draws its own noise and advances the caller's 16-byte state) through the
+    allocation-free entry point: same outputs and same state advance as eve_gate_top2_fwd from the same state."""
+    dev = torch.device("cuda:0")
+    for S, E in [(15168, 32), (500, 32)]:
+        logits, _ = _inputs(S, E, 11, dev)
+        C = ops.capacity(S, E, 1.0, 4)
+        st_a = torch.tensor([1234, 77], dtype=torch.int64, device=dev)
+        st_b = st_a.clone()
+        got = _noalloc(logits, st_a, C, noise_is_uniform=ops.NOISE_DEVICE_PHILOX)
+        want = ops.gate_top2(logits, st_b, C, ops.NOISE_DEVICE_PHILOX)
+        torch.cuda.synchronize()
+        for name in FIELDS:
+            assert torch.equal(getattr(got, name), getattr(want, name)), (S, name)
+        assert torch.equal(st_a, st_b) and int(st_a[1]) == 77 + S * E // 4
