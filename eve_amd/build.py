@@ -55,7 +55,8 @@ def _stale(out: str) -> bool:
         return True
 
 
-def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False, variant: str = "", defines=()) -> str:
+def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False, variant: str = "", defines=(),
+          extra_flags=()) -> str:
     """`variant` + `defines`: an experimental build eve_amd/libeve_moe_<variant>.so with extra -D flags and the debug
     knobs (kernel A/B experiments; select it with EVE_MOE_LIB)."""
     out = OUT_DBG if debug_knobs else OUT
@@ -80,6 +81,8 @@ def build(force: bool = False, verbose: bool = True, debug_knobs: bool = False, 
             cmd.insert(-4, "-DEVE_FFN_DEBUG_KNOBS=1")
         for d in defines:
             cmd.insert(-4, "-D" + d)
+        for f in extra_flags:  # (variant builds only: compiler-option experiments)
+            cmd.insert(-4, f)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
@@ -99,4 +102,7 @@ if __name__ == "__main__":
     argv = sys.argv[1:]
     var = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
     defs = [argv[i + 1] for i, a in enumerate(argv) if a == "--define"]
-    build(force="--force" in argv, debug_knobs="--debug-knobs" in argv, variant=var, defines=defs)
+    flags = [argv[i + 1] for i, a in enumerate(argv) if a == "--flag"]
+    if flags and not var:
+        raise SystemExit("build.py: --flag is for --variant builds")
+    build(force="--force" in argv, debug_knobs="--debug-knobs" in argv, variant=var, defines=defs, extra_flags=flags)
