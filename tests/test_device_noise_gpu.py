@@ -124,3 +124,20 @@ def test_graph_replays_draw_fresh_noise_without_host_work():
         assert torch.equal(out, ro) and torch.equal(l_aux, rl)
         assert torch.equal(moe.moe.gate.wg.weight.grad, ref.moe.gate.wg.weight.grad)
     assert not torch.equal(slots[0], slots[1]) and not torch.equal(slots[1], slots[2])
+
+
+@pytest.mark.parametrize("offset", [(1 << 32) - 100, (1 << 32) + 7, (1 << 40) + 3, (1 << 63) - 50000])
+def test_counter_carries_into_the_high_word(offset):
+    """The Philox counter is the 64-bit offset + element / 4 in two 32-bit words: a draw that straddles 2^32 (reached
+    after ~35 000 cfg-2 steps) and large offsets must follow the numpy stream, and the advance must carry."""
+    S, E = 1000, 32
+    logits = torch.randn(S, E, generator=torch.Generator().manual_seed(3)).to(DEV)
+    C = ops.capacity(S, E, 1.0, 4)
+    src = DeviceNoise(DEV, seed=0x0123456789ABCDEF)
+    src.state[1] = offset
+    got = ops.gate_top2(logits, src.state, C, ops.NOISE_DEVICE_PHILOX)
+    u = torch.from_numpy(device_noise_uniforms(0x0123456789ABCDEF, offset, S, E)).to(DEV)
+    want = ops.gate_top2(logits, u, C, True)
+    for f in FIELDS:
+        assert torch.equal(getattr(got, f), getattr(want, f)), f
+    assert _state(src.state)[1] == offset + S * E // 4
